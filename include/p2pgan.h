@@ -1,0 +1,157 @@
+/*
+ * p2pgan.h -- C ABI of libp2pgan_hip.so: the MI355X (gfx950) kernels behind the Pix2Pix side2side
+ * training step of fegemo/palette-and-histo-gan.
+ *
+ * The reference has no FFI seam: its hot path bottoms out in TensorFlow/Keras ops called from Python
+ * (SURVEY.md section 8b).  Each entry point below replaces the TF op(s) at the cited reference call
+ * site; the Python host in palette_and_histo_gan_amd/ re-creates the reference class API
+ * (Pix2PixModel.train_step etc.) on top of them through ctypes.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers; the library never allocates or frees, workspaces are passed in;
+ *   - tensors are NHWC "views" (p2p_tensor): a pointer to element (n=0,y=0,x=0,c=0) of the view plus
+ *     pixel strides.  Activation buffers are allocated with a zero halo of 2 pixels around every image
+ *     so kernels read the SAME-padding taps without bounds checks, and several views may alias one
+ *     buffer with different channel offsets (concat-by-slice, networks.py:45,94);
+ *   - dtype selects the storage/MFMA-input type of activations and weight copies: P2P_F32 (parity
+ *     mode, exact-f32 MFMA) or P2P_BF16 (throughput mode, bf16 in / f32 accumulate).  Master weights,
+ *     gradients, optimizer state, statistics and loss partials are always f32;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, no hidden syncs;
+ *   - return 0 on success, otherwise a hipError_t / negative argument-check code; the message is
+ *     available from p2p_last_error() (thread-local).
+ *
+ * Stride-2 4x4 layers are described once by (hi, lo, W[16][Cg][Cd]):
+ *   Conv2D          (networks.py:10-16): hi = input  (2LH x 2LW x Cg), lo = output, W = HWIO kernel
+ *   Conv2DTranspose (networks.py:26-27): hi = output (2LH x 2LW x Cg), lo = input,  W = (kh,kw,Cout,Cin)
+ * so the Keras layouts of both layer kinds are the same [tap][Cg][Cd] array and
+ *   op G (hi -> lo): lo[n,y,x,d]  = sum_{kh,kw,g} hi[n,s*y+kh-1,s*x+kw-1,g] W[kh,kw,g,d]   conv fwd / convT dgrad
+ *   op P (lo -> hi): hi[n,Y,X,g]  = sum_{Y=s*y+kh-1, X=s*x+kw-1, d} lo[n,y,x,d] W[kh,kw,g,d] convT fwd / conv dgrad
+ *   op W           : dW[kh,kw,g,d] = sum_{n,y,x} hi[n,s*y+kh-1,s*x+kw-1,g] lo[n,y,x,d]     weight gradient
+ * The stride-1 layers (networks.py:47-48,75-78; TF SAME pad 1 before / 2 after) use the same forms with s=1.
+ */
+#ifndef P2PGAN_H
+#define P2PGAN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { P2P_F32 = 0, P2P_BF16 = 1 } p2p_dtype;
+typedef enum { P2P_OP_G = 0, P2P_OP_P = 1, P2P_OP_W = 2 } p2p_convop;
+typedef enum { P2P_ACT_NONE = 0, P2P_ACT_LEAKY = 1, P2P_ACT_RELU = 2 } p2p_act;
+
+typedef struct {
+    void* ptr;            /* element (0,0,0,0) of the view */
+    long long img_stride; /* pixels between images */
+    int row_stride;       /* pixels between rows */
+    int ld;               /* elements between pixels (channels of the underlying buffer) */
+} p2p_tensor;
+
+/* A gradient source read pointwise at (pixel, channel): kind 0 = absent, 1 = activation dtype,
+ * 2 = f32, possibly `nslabs` split-K slabs `slab_stride` elements apart that are summed on load.
+ * Dense [pixels][ld] layout, channel offset coff. */
+typedef struct {
+    const void* ptr;
+    int kind;
+    int nslabs;
+    long long slab_stride;
+    int ld;
+    int coff;
+} p2p_gsrc;
+
+const char* p2p_last_error(void);
+int p2p_version(void);
+
+/* ---- convolutions -------------------------------------------------------------------------- */
+
+/* Direct (non-MFMA) 4x4 convolution, any channel counts, stride 1 or 2: the edge layers
+ * (Cin 1..8, Cout 1..4; networks.py:46-48,57,75-78) and the on-device cross-check of the MFMA paths.
+ * op G/P write the output view in `dtype`; op W writes f32 dW[16][Cg][Cd] (and dbias[Cd] if non-null,
+ * = sum of lo).  `w` is the [16][Cg][Cd] weight copy in `dtype`; `bias` (f32[Cd], op G only) may be null. */
+int p2p_conv_direct(int op, int stride, int dtype, int N, int LH, int LW, int Cg, int Cd,
+                    const p2p_tensor* hi, const p2p_tensor* lo, const void* w, const float* bias,
+                    float* dw, float* dbias, void* stream);
+
+/* MFMA implicit-GEMM for the stride-2 blocks (networks.py:7-36), op G or P.
+ * Requires Cg % 32 == 0 and Cd % 32 == 0.  `w` is Wt[16][Cd][Cg] for op G and Wn[16][Cg][Cd] for op P
+ * (both produced by p2p_weight_prep).  The input view must carry the zero halo.  With splitk == 1 the
+ * result is written to the output view in `dtype`; with splitk > 1 (a divisor of 16 for G, of 4 for P)
+ * f32 partial slabs [splitk][pixels][Cout] are written to `slabs` and summed by the consumer
+ * (p2p_norm_act_fwd / p2p_gsrc). */
+int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd,
+              const p2p_tensor* hi, const p2p_tensor* lo, const void* w,
+              int splitk, float* slabs, void* stream);
+
+/* MFMA weight gradient of a stride-2 block: dw[16][Cg][Cd] (f32) = sum over pixels.  The pixel sum is
+ * split over `msplit` workgroups per tile; partial slabs go to `workspace`
+ * (p2p_wgemm_workspace_bytes) and are reduced deterministically. */
+long long p2p_wgemm_workspace_bytes(int N, int LH, int LW, int Cg, int Cd, int msplit);
+int p2p_wgemm(int dtype, int N, int LH, int LW, int Cg, int Cd,
+              const p2p_tensor* hi, const p2p_tensor* lo, float* dw,
+              int msplit, void* workspace, void* stream);
+
+/* ---- InstanceNorm + activation + dropout (networks.py:18-19,29-34), fused ---------------------- */
+
+/* raw: conv output, dense [N*H*W][C]; raw_kind 1 = `dtype`, 2 = f32 with nslabs split-K slabs.
+ * gamma/beta null => no normalisation (down1, D.down: networks.py:46,58).
+ * y = act(drop(gamma*(x-mu)*rsqrt(var+eps)+beta)), dropout keep-mask `mask` (u8 dense [N*H*W][C], may be
+ * null) scales kept values by 2.  Writes y into the (haloed, possibly channel-sliced) view `out`,
+ * mean/rstd into stats[N][C][2] and, if raw_out != null, the summed raw tensor in `dtype`. */
+int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C,
+                     const void* raw, int raw_kind, int nslabs, long long slab_stride,
+                     const float* gamma, const float* beta, float eps, int act, float alpha,
+                     const unsigned char* mask, const p2p_tensor* out, void* raw_out, float* stats,
+                     void* stream);
+
+/* Backward of the fused block: dact = g1 + g2 (pointwise gradient sources), through dropout/activation
+ * (sign recomputed from raw+stats) and the InstanceNorm closed form.  Writes d(raw)
+ * into the haloed view `draw` and per-image partials dgamma_part/dbeta_part [N][C] (f32). */
+int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C,
+                     const void* raw, const float* stats, const float* gamma, const float* beta,
+                     int act, float alpha, const unsigned char* mask,
+                     const p2p_gsrc* g1, const p2p_gsrc* g2,
+                     const p2p_tensor* draw, float* dgamma_part, float* dbeta_part, void* stream);
+
+/* out[c] = scale * sum_r part[r][c] (f32): batch reduction of dgamma/dbeta partials, loss partials. */
+int p2p_colsum(const float* part, int rows, int cols, float scale, float* out, void* stream);
+
+/* ---- losses (pix2pix_model.py:44-56) ------------------------------------------------------------ */
+
+/* logits: view [N2][H][W][1]; images [0,n_real) are D(real), the rest D(fake).
+ * loss_out[0..2] = sums of BCE(1,real), BCE(0,fake), BCE(1,fake) scaled by inv_count.
+ * dlogits_d (all N2 images): d(real+fake loss)/dlogit; dlogits_g (fake images only): d(adv)/dlogit. */
+int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits,
+                   float inv_count, const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g,
+                   float* loss_out, void* stream);
+
+/* fake = tanh(z) written to `fake` view; l1_out[0] = inv_count * sum |real - fake| over all C channels. */
+int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* real,
+                    const p2p_tensor* fake, float inv_count, float* l1_out, void* stream);
+
+/* dz = (g_d + g_extra + lambda_l1*inv_count*sign(fake-real)) * (1 - fake^2) into the haloed view dz. */
+int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
+                    const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale,
+                    const p2p_tensor* dz, void* stream);
+
+/* ---- optimizer / parameter plumbing (pix2pix_model.py:28-29,81-83) ------------------------------- */
+
+/* Keras Adam over a flat f32 buffer; t = iteration AFTER increment; grads are multiplied by gscale first. */
+int p2p_adam_flat(float* p, const float* g, float* m, float* v, long long n, int t,
+                  float lr, float beta1, float beta2, float eps, float gscale, void* stream);
+
+/* master f32 W[16][Cg][Cd] -> wn (dtype, same layout; may be null) and wt (dtype, [16][Cd][Cg]; may be null). */
+int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* wn, void* wt, void* stream);
+
+/* dense f32 (or i32 if src_is_int) [N][H][W][C] host-layout batch -> view in `dtype` (dataset_utils.py:39-48 contract). */
+int p2p_pack_input(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
+                   const p2p_tensor* dst, void* stream);
+/* view in `dtype` -> dense f32 [N][H][W][C] (for generate()/tests). */
+int p2p_unpack(int dtype, int N, int H, int W, int C, const p2p_tensor* src, float* dst, void* stream);
+
+/* Bernoulli(0.5) keep mask of Dropout(0.5) (networks.py:31-32): counter-based RNG, one byte per element. */
+int p2p_dropout_mask(unsigned char* mask, long long n, long long seed, long long counter, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

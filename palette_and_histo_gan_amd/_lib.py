@@ -1,0 +1,83 @@
+"""ctypes binding of libp2pgan_hip.so (include/p2pgan.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libp2pgan_hip.so")
+
+F32, BF16 = 0, 1
+OP_G, OP_P, OP_W = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+
+
+class Tensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("img_stride", C.c_longlong), ("row_stride", C.c_int), ("ld", C.c_int)]
+
+
+class GSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("kind", C.c_int), ("nslabs", C.c_int), ("slab_stride", C.c_longlong),
+                ("ld", C.c_int), ("coff", C.c_int)]
+
+
+_TP = C.POINTER(Tensor)
+_GP = C.POINTER(GSrc)
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> argtypes; every function returns int except the two noted below
+SIGNATURES = {
+    "p2p_conv_direct": [_i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp, _vp, _vp],
+    "p2p_igemm": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
+    "p2p_wgemm": [_i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
+    "p2p_norm_act_fwd": [_i, _i, _i, _i, _i, _vp, _i, _i, _ll, _vp, _vp, _f, _i, _f, _vp, _TP, _vp, _vp, _vp],
+    "p2p_norm_act_bwd": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _GP, _GP, _TP, _vp, _vp, _vp],
+    "p2p_colsum": [_vp, _i, _i, _f, _vp, _vp],
+    "p2p_bce_logits": [_i, _i, _i, _i, _i, _TP, _f, _TP, _TP, _vp, _vp],
+    "p2p_tanh_l1_fwd": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp],
+    "p2p_tanh_l1_bwd": [_i, _i, _i, _i, _i, _TP, _TP, _GP, _GP, _f, _TP, _vp],
+    "p2p_adam_flat": [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp],
+    "p2p_weight_prep": [_i, _vp, _i, _i, _vp, _vp, _vp],
+    "p2p_pack_input": [_i, _i, _i, _i, _i, _vp, _i, _TP, _vp],
+    "p2p_unpack": [_i, _i, _i, _i, _i, _TP, _vp, _vp],
+    "p2p_dropout_mask": [_vp, _ll, _ll, _ll, _vp],
+}
+SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
+           "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong)}
+
+_lib = None
+
+
+class P2PError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared library once; raises if it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise P2PError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        for name, (argtypes, restype) in SPECIAL.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise P2PError(f"{name} failed (rc={rc}): {lib().p2p_last_error().decode()}")
+
+
+def exported_symbols():
+    return list(SIGNATURES) + list(SPECIAL)

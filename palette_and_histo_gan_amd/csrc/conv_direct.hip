@@ -1,0 +1,175 @@
+// Direct 4x4 convolution (no MFMA): edge layers with tiny channel counts and the on-device cross-check
+// of the implicit-GEMM kernels.  Reference ops: Conv2D / Conv2DTranspose and their tape gradients at
+// networks.py:10-16,26-27,46-48,75-78.  Forms G / P / W are defined in include/p2pgan.h.
+#include "p2p_common.hpp"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void p2p_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int p2p_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        p2p_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" const char* p2p_last_error(void) { return g_err; }
+extern "C" int p2p_version(void) { return 1; }
+
+// ---- op G: lo[m][d] = bias[d] + sum_{t,g} hi[pix(m,t)][g] * w[t][g][d] ------------------------------
+template <typename T>
+__global__ void conv_direct_G(int stride, int N, int LH, int LW, int Cg, int Cd, TView hi, TView lo,
+                              const T* __restrict__ w, const float* __restrict__ bias) {
+    long long total = (long long)N * LH * LW * Cd;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int d = (int)(idx % Cd);
+    long long m = idx / Cd;
+    int x = (int)(m % LW);
+    int y = (int)((m / LW) % LH);
+    int n = (int)(m / ((long long)LW * LH));
+    int HH = stride * LH, HW = stride * LW;
+    float acc = bias ? bias[d] : 0.f;
+    for (int kh = 0; kh < 4; ++kh) {
+        int ih = stride * y + kh - 1;
+        if (ih < 0 || ih >= HH) continue;
+        for (int kw = 0; kw < 4; ++kw) {
+            int iw = stride * x + kw - 1;
+            if (iw < 0 || iw >= HW) continue;
+            const T* hp = (const T*)hi.ptr + hi.off(n, ih, iw);
+            const T* wp = w + (long long)(kh * 4 + kw) * Cg * Cd + d;
+            for (int g = 0; g < Cg; ++g) acc += to_f32(hp[g]) * to_f32(wp[(long long)g * Cd]);
+        }
+    }
+    ((T*)lo.ptr)[lo.off(n, y, x) + d] = from_f32<T>(acc);
+}
+
+// ---- op P: hi[n,Y,X,g] = sum_{t: Y=s*y+kh-1, X=s*x+kw-1} sum_d lo[n,y,x,d] * w[t][g][d] --------------
+template <typename T>
+__global__ void conv_direct_P(int stride, int N, int LH, int LW, int Cg, int Cd, TView hi, TView lo,
+                              const T* __restrict__ w) {
+    int HH = stride * LH, HW = stride * LW;
+    long long total = (long long)N * HH * HW * Cg;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int g = (int)(idx % Cg);
+    long long p = idx / Cg;
+    int X = (int)(p % HW);
+    int Y = (int)((p / HW) % HH);
+    int n = (int)(p / ((long long)HW * HH));
+    float acc = 0.f;
+    for (int kh = 0; kh < 4; ++kh) {
+        int ty = Y + 1 - kh;
+        if (ty < 0 || (ty % stride) != 0) continue;
+        int y = ty / stride;
+        if (y >= LH) continue;
+        for (int kw = 0; kw < 4; ++kw) {
+            int tx = X + 1 - kw;
+            if (tx < 0 || (tx % stride) != 0) continue;
+            int x = tx / stride;
+            if (x >= LW) continue;
+            const T* lp = (const T*)lo.ptr + lo.off(n, y, x);
+            const T* wp = w + ((long long)(kh * 4 + kw) * Cg + g) * Cd;
+            for (int d = 0; d < Cd; ++d) acc += to_f32(lp[d]) * to_f32(wp[d]);
+        }
+    }
+    ((T*)hi.ptr)[hi.off(n, Y, X) + g] = from_f32<T>(acc);
+}
+
+// ---- op W: dw[t][g][d] += sum over a chunk of pixels; grid.y = pixel chunks, atomics into dw ---------
+template <typename T>
+__global__ void conv_direct_W(int stride, int N, int LH, int LW, int Cg, int Cd, TView hi, TView lo,
+                              float* __restrict__ dw, int chunk) {
+    int total = 16 * Cg * Cd;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int d = idx % Cd;
+    int g = (idx / Cd) % Cg;
+    int t = idx / (Cd * Cg);
+    int kh = t >> 2, kw = t & 3;
+    int HH = stride * LH, HW = stride * LW;
+    long long M = (long long)N * LH * LW;
+    long long m0 = (long long)blockIdx.y * chunk;
+    long long m1 = m0 + chunk < M ? m0 + chunk : M;
+    float acc = 0.f;
+    for (long long m = m0; m < m1; ++m) {
+        int x = (int)(m % LW);
+        int y = (int)((m / LW) % LH);
+        int n = (int)(m / ((long long)LW * LH));
+        int ih = stride * y + kh - 1, iw = stride * x + kw - 1;
+        if (ih < 0 || ih >= HH || iw < 0 || iw >= HW) continue;
+        acc += to_f32(((const T*)hi.ptr)[hi.off(n, ih, iw) + g]) * to_f32(((const T*)lo.ptr)[lo.off(n, y, x) + d]);
+    }
+    atomicAdd(dw + idx, acc);
+}
+
+// dbias[d] += sum over pixel chunk of lo[m][d]
+template <typename T>
+__global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk) {
+    __shared__ float red[16];
+    long long M = (long long)N * LH * LW;
+    long long m0 = (long long)blockIdx.x * chunk;
+    long long m1 = m0 + chunk < M ? m0 + chunk : M;
+    for (int d = 0; d < Cd; ++d) {
+        float acc = 0.f;
+        for (long long m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
+            int x = (int)(m % LW);
+            int y = (int)((m / LW) % LH);
+            int n = (int)(m / ((long long)LW * LH));
+            acc += to_f32(((const T*)lo.ptr)[lo.off(n, y, x) + d]);
+        }
+        float s = block_sum(acc, red);
+        if (threadIdx.x == 0) atomicAdd(out + d, s);
+    }
+}
+
+template <typename T>
+static int conv_direct_impl(int op, int stride, int N, int LH, int LW, int Cg, int Cd, TView hi, TView lo,
+                            const void* w, const float* bias, float* dw, float* dbias, hipStream_t st) {
+    const int TB = 256;
+    if (op == P2P_OP_G) {
+        long long total = (long long)N * LH * LW * Cd;
+        conv_direct_G<T><<<dim3((unsigned)((total + TB - 1) / TB)), TB, 0, st>>>(stride, N, LH, LW, Cg, Cd, hi, lo,
+                                                                               (const T*)w, bias);
+    } else if (op == P2P_OP_P) {
+        long long total = (long long)N * stride * LH * stride * LW * Cg;
+        conv_direct_P<T><<<dim3((unsigned)((total + TB - 1) / TB)), TB, 0, st>>>(stride, N, LH, LW, Cg, Cd, hi, lo,
+                                                                               (const T*)w);
+    } else {
+        long long M = (long long)N * LH * LW;
+        int total = 16 * Cg * Cd;
+        int chunk = 512;
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)total, st);
+        if (e != hipSuccess) { p2p_set_error("memset dw: %s", hipGetErrorString(e)); return (int)e; }
+        dim3 grid((total + TB - 1) / TB, (unsigned)((M + chunk - 1) / chunk));
+        conv_direct_W<T><<<grid, TB, 0, st>>>(stride, N, LH, LW, Cg, Cd, hi, lo, dw, chunk);
+        if (dbias) {
+            e = hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cd, st);
+            if (e != hipSuccess) { p2p_set_error("memset dbias: %s", hipGetErrorString(e)); return (int)e; }
+            int c2 = 4096;
+            view_colsum<T><<<dim3((unsigned)((M + c2 - 1) / c2)), TB, 0, st>>>(N, LH, LW, Cd, lo, dbias, c2);
+        }
+    }
+    return p2p_check_launch("p2p_conv_direct");
+}
+
+extern "C" int p2p_conv_direct(int op, int stride, int dtype, int N, int LH, int LW, int Cg, int Cd,
+                               const p2p_tensor* hi, const p2p_tensor* lo, const void* w, const float* bias,
+                               float* dw, float* dbias, void* stream) {
+    P2P_REQUIRE(op >= 0 && op <= 2, "p2p_conv_direct: bad op %d", op);
+    P2P_REQUIRE(stride == 1 || stride == 2, "p2p_conv_direct: stride must be 1 or 2, got %d", stride);
+    P2P_REQUIRE(N > 0 && LH > 0 && LW > 0 && Cg > 0 && Cd > 0, "p2p_conv_direct: bad shape");
+    P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr, "p2p_conv_direct: null tensor");
+    P2P_REQUIRE(op == P2P_OP_W ? dw != nullptr : w != nullptr, "p2p_conv_direct: null weight pointer");
+    P2P_DISPATCH_DTYPE(dtype, return conv_direct_impl<T>(op, stride, N, LH, LW, Cg, Cd, make_view(hi), make_view(lo), w,
+                                                         bias, dw, dbias, (hipStream_t)stream));
+}

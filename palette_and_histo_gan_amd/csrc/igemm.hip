@@ -1,0 +1,249 @@
+// MFMA implicit GEMM for the 4x4 stride-2 encoder/decoder blocks (Conv2D / Conv2DTranspose forward and
+// their data gradients; reference call sites networks.py:10-16,26-27 and the tape gradients taken at
+// pix2pix_model.py:78).  Forms (include/p2pgan.h):
+//   op G: lo[m][d] = sum_{t=(kh,kw)} sum_g hi[n,2y+kh-1,2x+kw-1,g] * Wt[t][d][g]      (16 taps)
+//   op P: hi[n,2y+ph,2x+pw][g] = sum_{2x2 taps of phase (ph,pw)} sum_d lo[n,y+dy,x+dx,d] * Wn[t][g][d]
+// Both are "NT" GEMMs  C[m][n] = sum_k A[m][k] B[n][k]:  A rows are gathered 128-byte runs of one input
+// pixel's channels (the zero halo around every image supplies the SAME padding, so no bounds checks),
+// B rows are 128-byte runs of one output channel's weights.
+//
+// Tiling (CDNA4, wave64): 256 threads = 4 waves; block tile BM x BN, wave tile (TM x TN) 32x32 MFMA tiles,
+// K-block = 128 bytes per row (64 bf16 / 32 f32).  A and B tiles are staged global->LDS with
+// global_load_lds_dwordx4 (no VGPR round trip); the LDS image is lane-linear, so the bank swizzle
+// (16-byte slot ^= (row>>1)&7, conflict-free for ds_read_b128 MFMA operand reads) is applied to the
+// per-lane SOURCE address and again on the read.  Double-buffered: one barrier per K-block, the loads of
+// block k+1 are in flight while block k is multiplied.
+//   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.   f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact f32).
+#include "p2p_common.hpp"
+
+struct IgemmArgs {
+    const char* in; long long in_img; int in_row; int in_ld;      // gathered input view (element strides)
+    char* out; long long out_img; int out_row; int out_ld;        // output view, splitk == 1
+    float* slabs; long long slab_stride;                           // splitk > 1: f32 [ks][pixels][ncols]
+    const char* w;                                                  // [16][ncols][C] in T
+    int M, lgLW, lgLH, LW, LH;
+    int C, lgCB;         // contraction channels per tap, log2(C*sizeof(T))
+    int ncols;           // output channels
+    int op, splitk, taps_per;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+__device__ __forceinline__ void mfma_step(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_step(f32x16& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM / 32, NB = BN / 32;       // rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ks = blockIdx.z % a.splitk, phase = blockIdx.z / a.splitk;
+    const int ph = phase >> 1, pw = phase & 1;
+    const int tap_begin = ks * a.taps_per;
+    const int CB = 1 << a.lgCB;                       // bytes per tap row
+    const int nkb = (a.taps_per << a.lgCB) >> 7;      // K-blocks of 128 bytes
+    const long long esz = sizeof(T);
+
+    // ---- per-thread staging rows -------------------------------------------------------------------
+    long long abase[NA];   // byte offset of the row's base pixel in the input view
+    int aq[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int r = (i * 4 + wave) * 8 + (lane >> 3);
+        int m = min(m0 + r, a.M - 1);
+        int x = m & (a.LW - 1);
+        int y = (m >> a.lgLW) & (a.LH - 1);
+        int n = m >> (a.lgLW + a.lgLH);
+        int by = a.op == P2P_OP_G ? 2 * y - 1 : y;
+        int bx = a.op == P2P_OP_G ? 2 * x - 1 : x;
+        abase[i] = ((long long)n * a.in_img + (long long)by * a.in_row + bx) * a.in_ld * esz;
+        aq[i] = (lane & 7) ^ ((r >> 1) & 7);
+    }
+    int bq[NB];
+    long long bbase[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int r = (j * 4 + wave) * 8 + (lane >> 3);
+        bq[j] = (lane & 7) ^ ((r >> 1) & 7);
+        bbase[j] = (long long)(n0 + r) * a.C * esz;
+    }
+    const long long wtap = (long long)a.ncols * a.C * esz;   // bytes per weight tap slab
+
+    auto stage = [&](int kb, char* buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int kbyte = (kb << 7) + (aq[i] << 4);
+            int tl = tap_begin + (kbyte >> a.lgCB);
+            int cbyte = kbyte & (CB - 1);
+            int dy, dx;
+            if (a.op == P2P_OP_G) { dy = tl >> 2; dx = tl & 3; }
+            else { int kh = (1 - ph) + 2 * (tl >> 1), kw = (1 - pw) + 2 * (tl & 1); dy = (ph + 1 - kh) >> 1; dx = (pw + 1 - kw) >> 1; }
+            const char* src = a.in + abase[i] + ((long long)dy * a.in_row + dx) * a.in_ld * esz + cbyte;
+            glds16(src, buf + (i * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int kbyte = (kb << 7) + (bq[j] << 4);
+            int tl = tap_begin + (kbyte >> a.lgCB);
+            int cbyte = kbyte & (CB - 1);
+            int widx;
+            if (a.op == P2P_OP_G) widx = tl;
+            else widx = ((1 - ph) + 2 * (tl >> 1)) * 4 + (1 - pw) + 2 * (tl & 1);
+            const char* src = a.w + widx * wtap + bbase[j] + cbyte;
+            glds16(src, buf + A_BYTES + (j * 4 + wave) * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment read offsets (row part); the k-step part is XORed in
+    int arow[TM], brow[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) arow[i] = (wm * TM + i) * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) brow[j] = (wn * TN + j) * 32 + (lane & 31);
+    const int h = lane >> 5;
+
+    typedef typename Frag<T>::type frag_t;
+
+    stage(0, smem);
+    for (int kb = 0; kb < nkb; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        char* cur = smem + (kb & 1) * STAGE;
+        if (kb + 1 < nkb) stage(kb + 1, smem + ((kb + 1) & 1) * STAGE);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            frag_t af[TM], bf[TN];
+            const int q = 2 * s + h;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *(const frag_t*)(cur + arow[i] * 128 + ((q ^ ((arow[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *(const frag_t*)(cur + A_BYTES + brow[j] * 128 + ((q ^ ((brow[j] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mfma_step(acc[i][j], af[i], bf[j]);
+        }
+    }
+
+    // ---- epilogue: D[row = m][col = n], col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m >= a.M) continue;
+            long long pix;
+            if (a.op == P2P_OP_G) {
+                int x = m & (a.LW - 1);
+                int y = (m >> a.lgLW) & (a.LH - 1);
+                int n = m >> (a.lgLW + a.lgLH);
+                pix = (long long)n * a.out_img + (long long)y * a.out_row + x;
+            } else {
+                int x = m & (a.LW - 1);
+                int y = (m >> a.lgLW) & (a.LH - 1);
+                int n = m >> (a.lgLW + a.lgLH);
+                pix = (long long)n * a.out_img + (long long)(2 * y + ph) * a.out_row + (2 * x + pw);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+                if (a.splitk == 1) ((T*)a.out)[pix * a.out_ld + col] = from_f32<T>(acc[i][j][e]);
+                else a.slabs[(long long)ks * a.slab_stride + pix * a.out_ld + col] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+static int ilog2_exact(long long v) {
+    int l = 0;
+    while ((1LL << l) < v) ++l;
+    return (1LL << l) == v ? l : -1;
+}
+
+template <typename T>
+static int igemm_launch(IgemmArgs& a, int phases, hipStream_t st) {
+    dim3 block(256);
+    unsigned gz = (unsigned)(phases * a.splitk);
+    if (a.ncols % 128 == 0) {
+        constexpr int BM = 128, BN = 128;
+        dim3 grid((a.M + BM - 1) / BM, a.ncols / BN, gz);
+        igemm_kernel<T, 2, 2, 2, 2><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+    } else if (a.ncols % 64 == 0) {
+        constexpr int BM = 128, BN = 64;
+        dim3 grid((a.M + BM - 1) / BM, a.ncols / BN, gz);
+        igemm_kernel<T, 2, 2, 2, 1><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+    } else {
+        constexpr int BM = 128, BN = 32;
+        dim3 grid((a.M + BM - 1) / BM, a.ncols / BN, gz);
+        igemm_kernel<T, 4, 1, 1, 1><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+    }
+    return p2p_check_launch("p2p_igemm");
+}
+
+extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
+                         const p2p_tensor* lo, const void* w, int splitk, float* slabs, void* stream) {
+    P2P_REQUIRE(op == P2P_OP_G || op == P2P_OP_P, "p2p_igemm: op must be G or P");
+    P2P_REQUIRE(N > 0 && LH > 0 && LW > 0, "p2p_igemm: bad shape");
+    P2P_REQUIRE(Cg % 32 == 0 && Cd % 32 == 0 && Cg > 0 && Cd > 0, "p2p_igemm: Cg=%d, Cd=%d must be multiples of 32", Cg, Cd);
+    P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && w, "p2p_igemm: null pointer");
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    IgemmArgs a;
+    const p2p_tensor* in = op == P2P_OP_G ? hi : lo;
+    const p2p_tensor* out = op == P2P_OP_G ? lo : hi;
+    a.C = op == P2P_OP_G ? Cg : Cd;
+    a.ncols = op == P2P_OP_G ? Cd : Cg;
+    a.lgCB = ilog2_exact((long long)a.C * esz);
+    a.lgLW = ilog2_exact(LW);
+    a.lgLH = ilog2_exact(LH);
+    P2P_REQUIRE(a.lgCB >= 6, "p2p_igemm: contraction channels*elemsize must be a power of two >= 64 bytes (C=%d)", a.C);
+    P2P_REQUIRE(a.lgLW >= 0 && a.lgLH >= 0, "p2p_igemm: LH=%d, LW=%d must be powers of two", LH, LW);
+    P2P_REQUIRE((in->ld * esz) % 16 == 0 && ((uintptr_t)in->ptr % 16) == 0 && ((uintptr_t)w % 16) == 0,
+                "p2p_igemm: input pixels and weights must be 16-byte aligned");
+    const int ntaps = op == P2P_OP_G ? 16 : 4;
+    P2P_REQUIRE(splitk >= 1 && ntaps % splitk == 0, "p2p_igemm: splitk=%d must divide %d", splitk, ntaps);
+    a.taps_per = ntaps / splitk;
+    P2P_REQUIRE(((long long)a.taps_per << a.lgCB) % 128 == 0, "p2p_igemm: K per split must be a multiple of 128 bytes");
+    P2P_REQUIRE(splitk == 1 || slabs, "p2p_igemm: splitk > 1 needs a slab workspace");
+    a.in = (const char*)in->ptr; a.in_img = in->img_stride; a.in_row = in->row_stride; a.in_ld = in->ld;
+    a.out = (char*)out->ptr; a.out_img = out->img_stride; a.out_row = out->row_stride; a.out_ld = out->ld;
+    a.slabs = slabs;
+    const int OH = op == P2P_OP_G ? LH : 2 * LH, OW = op == P2P_OP_G ? LW : 2 * LW;
+    a.slab_stride = (long long)N * OH * OW * out->ld;
+    if (splitk > 1) {   // slabs are dense [pixels][ncols]
+        a.out_img = (long long)OH * OW; a.out_row = OW; a.out_ld = a.ncols;
+        a.slab_stride = (long long)N * OH * OW * a.ncols;
+    }
+    a.w = (const char*)w;
+    a.M = N * LH * LW; a.LW = LW; a.LH = LH;
+    a.op = op; a.splitk = splitk;
+    const int phases = op == P2P_OP_G ? 1 : 4;
+    P2P_DISPATCH_DTYPE(dtype, return igemm_launch<T>(a, phases, (hipStream_t)stream));
+}

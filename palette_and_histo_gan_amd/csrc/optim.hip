@@ -1,0 +1,135 @@
+// Keras Adam over the flat parameter buffer, weight-copy preparation and batch packing.
+// Reference: tf.keras.optimizers.Adam(0.0002, beta_1=0.5) applied at pix2pix_model.py:28-29,81-83
+// (OptimizerV2 formulation: eps added to sqrt(v) outside the bias correction);
+// batch value contract dataset_utils.py:39-48,209-246.
+#include "p2p_common.hpp"
+#include <math.h>
+
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
+                                 float gscale) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+extern "C" int p2p_adam_flat(float* p, const float* g, float* m, float* v, long long n, int t, float lr, float beta1,
+                             float beta2, float eps, float gscale, void* stream) {
+    P2P_REQUIRE(p && g && m && v && n > 0 && t >= 1, "p2p_adam_flat: bad args");
+    double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    adam_flat_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, (float)lr_t, beta1, beta2,
+                                                                             eps, gscale);
+    return p2p_check_launch("p2p_adam_flat");
+}
+
+// wn[t][g][d] = T(w[t][g][d]);  wt[t][d][g] = T(w[t][g][d])   (32x32 LDS tile transpose per tap)
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, T* __restrict__ wn, T* __restrict__ wt) {
+    __shared__ float tile[32][33];
+    int t = blockIdx.z;
+    int g0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
+    const float* wp = w + (long long)t * Cg * Cd;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int g = g0 + r, d = d0 + tx;
+        float val = (g < Cg && d < Cd) ? wp[(long long)g * Cd + d] : 0.f;
+        tile[r][tx] = val;
+        if (wn && g < Cg && d < Cd) wn[(long long)t * Cg * Cd + (long long)g * Cd + d] = from_f32<T>(val);
+    }
+    __syncthreads();
+    if (wt) {
+        for (int r = ty; r < 32; r += 8) {
+            int d = d0 + r, g = g0 + tx;
+            if (g < Cg && d < Cd) wt[(long long)t * Cg * Cd + (long long)d * Cg + g] = from_f32<T>(tile[tx][r]);
+        }
+    }
+}
+
+extern "C" int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* wn, void* wt, void* stream) {
+    P2P_REQUIRE(w && Cg > 0 && Cd > 0 && (wn || wt), "p2p_weight_prep: bad args");
+    dim3 grid((Cd + 31) / 32, (Cg + 31) / 32, 16);
+    P2P_DISPATCH_DTYPE(dtype, (weight_prep_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(w, Cg, Cd, (T*)wn, (T*)wt)));
+    return p2p_check_launch("p2p_weight_prep");
+}
+
+template <typename T>
+__global__ void pack_input_kernel(int N, int H, int W, int C, const void* __restrict__ src, int src_is_int, TView dst) {
+    long long total = (long long)N * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long p = i / C;
+        int x = (int)(p % W);
+        int y = (int)((p / W) % H);
+        int n = (int)(p / ((long long)W * H));
+        float v = src_is_int ? (float)((const int*)src)[i] : ((const float*)src)[i];
+        ((T*)dst.ptr)[dst.off(n, y, x) + c] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void unpack_kernel(int N, int H, int W, int C, TView src, float* __restrict__ dst) {
+    long long total = (long long)N * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long p = i / C;
+        int x = (int)(p % W);
+        int y = (int)((p / W) % H);
+        int n = (int)(p / ((long long)W * H));
+        dst[i] = to_f32(((const T*)src.ptr)[src.off(n, y, x) + c]);
+    }
+}
+
+static inline unsigned grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    return (unsigned)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
+}
+
+extern "C" int p2p_pack_input(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
+                              const p2p_tensor* dst, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && src && dst && dst->ptr, "p2p_pack_input: bad args");
+    P2P_DISPATCH_DTYPE(dtype, (pack_input_kernel<T><<<dim3(grid_for((long long)N * H * W * C)), 256, 0, (hipStream_t)stream>>>(
+                                  N, H, W, C, src, src_is_int, make_view(dst))));
+    return p2p_check_launch("p2p_pack_input");
+}
+
+extern "C" int p2p_unpack(int dtype, int N, int H, int W, int C, const p2p_tensor* src, float* dst, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && src && src->ptr && dst, "p2p_unpack: bad args");
+    P2P_DISPATCH_DTYPE(dtype, (unpack_kernel<T><<<dim3(grid_for((long long)N * H * W * C)), 256, 0, (hipStream_t)stream>>>(
+                                  N, H, W, C, make_view(src), dst)));
+    return p2p_check_launch("p2p_unpack");
+}
+
+// Bernoulli(0.5) keep mask of keras Dropout(0.5) (networks.py:31-32): counter-based (splitmix64 of
+// seed, call counter, element index), one byte per element, 8 elements per hash.
+__global__ void dropout_mask_kernel(unsigned char* __restrict__ mask, long long n, unsigned long long seed,
+                                    unsigned long long counter) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i * 8 < n; i += stride) {
+        unsigned long long z = seed * 0x9E3779B97F4A7C15ull + counter * 0xD1B54A32D192ED03ull + (unsigned long long)i;
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        for (int k = 0; k < 8 && i * 8 + k < n; ++k) mask[i * 8 + k] = (unsigned char)((z >> (8 * k + 3)) & 1ull);
+    }
+}
+
+extern "C" int p2p_dropout_mask(unsigned char* mask, long long n, long long seed, long long counter, void* stream) {
+    P2P_REQUIRE(mask && n > 0, "p2p_dropout_mask: bad args");
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    dropout_mask_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(mask, n, (unsigned long long)seed,
+                                                                                (unsigned long long)counter);
+    return p2p_check_launch("p2p_dropout_mask");
+}

@@ -1,0 +1,105 @@
+// Shared device/host helpers for libp2pgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/p2pgan.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+
+#define P2P_WAVE 64
+
+void p2p_set_error(const char* fmt, ...);
+int p2p_check_launch(const char* what);
+
+#define P2P_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            p2p_set_error(__VA_ARGS__);        \
+            return -1;                         \
+        }                                      \
+    } while (0)
+
+// Device-side copy of p2p_tensor (plain ints so it can be passed by value as a kernel argument).
+struct TView {
+    char* ptr;
+    long long img;
+    int row;
+    int ld;
+    __host__ __device__ long long off(int n, int y, int x) const {
+        return ((long long)n * img + (long long)y * row + x) * ld;
+    }
+};
+
+static inline TView make_view(const p2p_tensor* t) {
+    TView v;
+    v.ptr = (char*)t->ptr;
+    v.img = t->img_stride;
+    v.row = t->row_stride;
+    v.ld = t->ld;
+    return v;
+}
+
+struct GSrc {
+    const char* ptr;
+    int kind;     // 0 none, 1 activation dtype, 2 f32 (nslabs slabs)
+    int nslabs;
+    long long slab;
+    int ld;
+    int coff;
+};
+
+static inline GSrc make_gsrc(const p2p_gsrc* g) {
+    GSrc s;
+    if (!g) {
+        s.ptr = nullptr; s.kind = 0; s.nslabs = 0; s.slab = 0; s.ld = 0; s.coff = 0;
+        return s;
+    }
+    s.ptr = (const char*)g->ptr; s.kind = g->ptr ? g->kind : 0; s.nslabs = g->nslabs;
+    s.slab = g->slab_stride; s.ld = g->ld; s.coff = g->coff;
+    return s;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+// gradient source value at dense pixel index `pix`, channel c
+template <typename T>
+__device__ __forceinline__ float gsrc_load(const GSrc& g, long long pix, int c) {
+    if (g.kind == 0) return 0.f;
+    long long e = pix * g.ld + g.coff + c;
+    if (g.kind == 1) return to_f32(((const T*)g.ptr)[e]);
+    float s = 0.f;
+    const float* p = (const float*)g.ptr + e;
+    for (int k = 0; k < g.nslabs; ++k) s += p[(long long)k * g.slab];
+    return s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024, result valid in every thread; `red` is >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+#define P2P_DISPATCH_DTYPE(dtype, CALL)                         \
+    do {                                                        \
+        if ((dtype) == P2P_F32) { typedef float T; CALL; }      \
+        else if ((dtype) == P2P_BF16) { typedef bf16_t T; CALL; } \
+        else { p2p_set_error("bad dtype %d", (int)(dtype)); return -1; } \
+    } while (0)

@@ -1,0 +1,250 @@
+"""-m gpu: every HIP kernel against the CPU oracle on seeded inputs, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_graph as rg
+from oracle import np_restatement as npr
+from palette_and_histo_gan_amd import _lib as L
+from palette_and_histo_gan_amd import engine as E
+from tests import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+DTYPES = [L.F32, L.BF16]
+OUT_TOL = {L.F32: 2e-5, L.BF16: 6e-3}      # max-norm relative; bf16 = output rounding (2^-8) of f32-accumulated sums
+
+
+def oracle_ops(hi, lo, w, stride):
+    """(G, P, W) results of the (hi, lo, W[4,4,Cg,Cd]) layer description in float64."""
+    hi_t = torch.tensor(hi, dtype=F64, requires_grad=True)
+    w_t = torch.tensor(w, dtype=F64, requires_grad=True)
+    lo_t = torch.tensor(lo, dtype=F64)
+    if stride == 2:
+        g = rg.conv4x4_s2(hi_t, w_t)
+    else:
+        g = rg.conv4x4_s1_bias(hi_t, w_t, None)
+    (g * lo_t).sum().backward()
+    return g.detach().numpy(), hi_t.grad.numpy(), w_t.grad.numpy()
+
+
+def make_case(rng, n, lh, cg, cd, stride, dtype):
+    hi = U.q(rng.normal(size=(n, stride * lh, stride * lh, cg)), dtype)
+    lo = U.q(rng.normal(size=(n, lh, lh, cd)), dtype)
+    w = U.q(rng.normal(scale=0.05, size=(4, 4, cg, cd)), dtype)
+    return hi, lo, w
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lh,cg,cd,stride", [(2, 4, 4, 64, 2), (1, 8, 8, 3, 2), (2, 5, 36, 4, 1), (3, 4, 64, 1, 1),
+                                                (2, 1, 5, 7, 2), (1, 3, 2, 2, 2)])
+def test_conv_direct(dtype, n, lh, cg, cd, stride):
+    rng = np.random.default_rng(10)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, stride, dtype)
+    bias = rng.normal(size=cd).astype(np.float32)
+    g_ref, p_ref, w_ref = oracle_ops(hi, lo, w, stride)
+    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
+    w_d = U.dev(w.reshape(-1), U.tdt(dtype))
+    bias_d = U.dev(bias)
+    out_g = E.HaloBuf(n, lh, lh, cd, dtype, U.DEV)
+    L.call("p2p_conv_direct", L.OP_G, stride, dtype, n, lh, lh, cg, cd, C.byref(hi_b.view()), C.byref(out_g.view()),
+           U.ptr(w_d), U.ptr(bias_d), None, None, U.stream())
+    assert U.rel_err(U.halo_to_np(out_g), g_ref + bias) < OUT_TOL[dtype]
+    out_p = E.DenseBuf(n, stride * lh, stride * lh, cg, U.tdt(dtype), U.DEV)
+    L.call("p2p_conv_direct", L.OP_P, stride, dtype, n, lh, lh, cg, cd, C.byref(out_p.view()), C.byref(lo_b.view()),
+           U.ptr(w_d), None, None, None, U.stream())
+    assert U.rel_err(U.dense_to_np(out_p), p_ref) < OUT_TOL[dtype]
+    dw = torch.empty(16 * cg * cd, dtype=torch.float32, device=U.DEV)
+    db = torch.empty(cd, dtype=torch.float32, device=U.DEV)
+    L.call("p2p_conv_direct", L.OP_W, stride, dtype, n, lh, lh, cg, cd, C.byref(hi_b.view()), C.byref(lo_b.view()),
+           None, None, U.ptr(dw), U.ptr(db), U.stream())
+    assert U.rel_err(dw.cpu().numpy().reshape(4, 4, cg, cd), w_ref) < 2e-5
+    assert U.rel_err(db.cpu().numpy(), lo.astype(np.float64).sum(axis=(0, 1, 2))) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lh,cg,cd,splitk", [(2, 4, 64, 128, 1), (3, 8, 32, 64, 1), (2, 2, 128, 256, 2), (1, 1, 512, 512, 4),
+                                                (5, 16, 32, 128, 1), (2, 4, 256, 32, 1), (2, 8, 64, 64, 2)])
+def test_igemm_ops_G_and_P(dtype, n, lh, cg, cd, splitk):
+    rng = np.random.default_rng(11)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, 2, dtype)
+    g_ref, p_ref, _ = oracle_ops(hi, lo, w, 2)
+    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
+    wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    L.call("p2p_weight_prep", dtype, U.ptr(U.dev(w.reshape(-1))), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
+    assert np.array_equal(wn.float().cpu().numpy().reshape(16, cg, cd), w.reshape(16, cg, cd))
+    assert np.array_equal(wt.float().cpu().numpy().reshape(16, cd, cg), w.reshape(16, cg, cd).transpose(0, 2, 1))
+    esz = 2 if dtype == L.BF16 else 4
+    for op, ref, shape in ((L.OP_G, g_ref, (n, lh, lh, cd)), (L.OP_P, p_ref, (n, 2 * lh, 2 * lh, cg))):
+        ntaps = 16 if op == L.OP_G else 4
+        cc = cg if op == L.OP_G else cd
+        sk = splitk
+        while sk > 1 and (ntaps % sk or ((ntaps // sk) * cc * esz) % 128):
+            sk //= 2
+        out = E.DenseBuf(*shape, U.tdt(dtype), U.DEV)
+        out.t.fill_(float("nan"))
+        slabs = torch.full((max(sk, 1) * int(np.prod(shape)),), float("nan"), dtype=torch.float32, device=U.DEV)
+        hv, lv = (hi_b.view(), out.view()) if op == L.OP_G else (out.view(), lo_b.view())
+        L.call("p2p_igemm", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn),
+               sk, U.ptr(slabs) if sk > 1 else None, U.stream())
+        got = U.dense_to_np(out) if sk == 1 else slabs.view(sk, *shape).sum(0).cpu().numpy()
+        tol = OUT_TOL[dtype] if sk == 1 else 2e-5
+        assert U.rel_err(got, ref) < tol, (op, sk)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lh,cg,cd,msplit", [(2, 4, 32, 128, 1), (2, 8, 64, 128, 2), (3, 4, 128, 256, 1), (1, 1, 128, 128, 1),
+                                                (2, 16, 32, 128, 4), (5, 2, 64, 256, 1)])
+def test_wgemm(dtype, n, lh, cg, cd, msplit):
+    rng = np.random.default_rng(12)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, 2, dtype)
+    _, _, w_ref = oracle_ops(hi, lo, w, 2)
+    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
+    dw = torch.full((16 * cg * cd,), float("nan"), dtype=torch.float32, device=U.DEV)
+    ws_bytes = L.lib().p2p_wgemm_workspace_bytes(n, lh, lh, cg, cd, msplit)
+    ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_wgemm", dtype, n, lh, lh, cg, cd, C.byref(hi_b.view()), C.byref(lo_b.view()), U.ptr(dw), msplit,
+           U.ptr(ws), U.stream())
+    assert U.rel_err(dw.cpu().numpy().reshape(4, 4, cg, cd), w_ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,c,act,use_mask,norm", [(2, 4, 64, L.ACT_LEAKY, False, True), (3, 8, 32, L.ACT_RELU, True, True),
+                                                      (2, 1, 512, L.ACT_LEAKY, False, True), (2, 4, 36, L.ACT_RELU, True, True),
+                                                      (2, 8, 64, L.ACT_LEAKY, False, False)])
+def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm):
+    rng = np.random.default_rng(13)
+    x = U.q(rng.normal(size=(n, h, h, c)) * 2 + 0.3, dtype)
+    gamma = (1 + 0.2 * rng.normal(size=c)).astype(np.float32)
+    beta = (0.2 * rng.normal(size=c)).astype(np.float32)
+    mask = rng.integers(0, 2, size=(n, h, h, c)).astype(np.uint8) if use_mask else None
+    dy1 = U.q(rng.normal(size=(n, h, h, c + 8)), dtype)       # gradient sources with channel offset / f32 slabs
+    dy2 = rng.normal(size=(2, n, h, h, c)).astype(np.float32)
+    xt = torch.tensor(x, dtype=F64, requires_grad=True)
+    gt = torch.tensor(gamma, dtype=F64, requires_grad=True)
+    bt = torch.tensor(beta, dtype=F64, requires_grad=True)
+    y = rg.instance_norm(xt, gt, bt) if norm else xt
+    if use_mask:
+        y = rg.dropout(y, torch.tensor(mask, dtype=F64))
+    y = rg.leaky_relu(y) if act == L.ACT_LEAKY else torch.relu(y)
+    dy = torch.tensor(dy1[..., 8:], dtype=F64) + torch.tensor(dy2.sum(0), dtype=F64)
+    (y * dy).sum().backward()
+
+    raw = E.DenseBuf(n, h, h, c, U.tdt(dtype), U.DEV)
+    raw.t.copy_(U.dev(x.reshape(-1, c), U.tdt(dtype)))
+    out = E.HaloBuf(n, h, h, c + 4, dtype, U.DEV)
+    stats = torch.empty((n, c, 2), dtype=torch.float32, device=U.DEV)
+    g_d, b_d = U.dev(gamma), U.dev(beta)
+    mask_d = U.dev(mask.reshape(-1, c), torch.uint8) if use_mask else None
+    L.call("p2p_norm_act_fwd", dtype, n, h, h, c, raw.ptr(), 1, 1, 0, U.ptr(g_d) if norm else None,
+           U.ptr(b_d) if norm else None, 1e-3, act, 0.3, U.ptr(mask_d) if use_mask else None, C.byref(out.view(coff=4)),
+           None, U.ptr(stats) if norm else None, U.stream())
+    got = U.halo_to_np(out)
+    assert np.count_nonzero(got[..., :4]) == 0
+    assert U.rel_err(got[..., 4:], y.detach().numpy()) < OUT_TOL[dtype]
+    assert float(out.t.float().abs().sum()) == pytest.approx(float(np.abs(got).sum()), rel=1e-6)   # halo untouched
+
+    g1 = E.DenseBuf(n, h, h, c + 8, U.tdt(dtype), U.DEV)
+    g1.t.copy_(U.dev(dy1.reshape(-1, c + 8), U.tdt(dtype)))
+    g2 = U.dev(dy2.reshape(-1))
+    gs2 = L.GSrc(g2.data_ptr(), 2, 2, n * h * h * c, c, 0)
+    draw = E.HaloBuf(n, h, h, c, dtype, U.DEV)
+    part = torch.zeros((2, n, c), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_norm_act_bwd", dtype, n, h, h, c, raw.ptr(), U.ptr(stats) if norm else None,
+           U.ptr(g_d) if norm else None, U.ptr(b_d) if norm else None, act, 0.3, U.ptr(mask_d) if use_mask else None,
+           C.byref(g1.gsrc(coff=8)), C.byref(gs2), C.byref(draw.view()), U.ptr(part[1]) if norm else None,
+           U.ptr(part[0]) if norm else None, U.stream())
+    ref_dx = xt.grad.numpy()
+    scale = np.abs(ref_dx).max() + 1e-30
+    assert np.abs(U.halo_to_np(draw) - ref_dx).max() / scale < (1e-4 if dtype == L.F32 else 1e-2)
+    if norm:
+        dgam = torch.empty(c, dtype=torch.float32, device=U.DEV)
+        dbet = torch.empty(c, dtype=torch.float32, device=U.DEV)
+        L.call("p2p_colsum", U.ptr(part[1]), n, c, 1.0, U.ptr(dgam), U.stream())
+        L.call("p2p_colsum", U.ptr(part[0]), n, c, 1.0, U.ptr(dbet), U.stream())
+        assert U.rel_err(dgam.cpu().numpy(), gt.grad.numpy()) < 1e-4
+        assert U.rel_err(dbet.cpu().numpy(), bt.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_losses(dtype):
+    rng = np.random.default_rng(14)
+    n2, nr, h = 6, 3, 8
+    logits = U.q(rng.normal(size=(n2, h, h, 1)) * 3, dtype)
+    lb = U.halo_from(logits, dtype)
+    dld, dlg = E.HaloBuf(n2, h, h, 1, dtype, U.DEV), E.HaloBuf(n2 - nr, h, h, 1, dtype, U.DEV)
+    loss = torch.zeros(8, dtype=torch.float32, device=U.DEV)
+    inv = 1.0 / (nr * h * h)
+    L.call("p2p_bce_logits", dtype, n2, nr, h, h, C.byref(lb.view()), inv, C.byref(dld.view()), C.byref(dlg.view()),
+           U.ptr(loss), U.stream())
+    lt = torch.tensor(logits, dtype=F64, requires_grad=True)
+    real, fake, adv = rg.bce_from_logits(lt[:nr], 1.0), rg.bce_from_logits(lt[nr:], 0.0), rg.bce_from_logits(lt[nr:], 1.0)
+    got = loss.cpu().numpy()
+    np.testing.assert_allclose(got[:3], [float(real), float(fake), float(adv)], rtol=1e-5)
+    gd = torch.autograd.grad(real + fake, lt, retain_graph=True)[0].numpy()
+    gg = torch.autograd.grad(adv, lt)[0].numpy()[nr:]
+    tol = 1e-5 if dtype == L.F32 else 6e-3
+    assert U.rel_err(U.halo_to_np(dld), gd) < tol
+    assert U.rel_err(U.halo_to_np(dlg), gg) < tol
+
+    n, s, c = 2, 8, 4
+    z = U.q(rng.normal(size=(n, s, s, c)), dtype)
+    real_img = U.q(rng.uniform(-1, 1, size=(n, s, s, c)), dtype)
+    gd_src = U.q(rng.normal(size=(n, s, s, 8)), dtype)
+    zb, rb = U.halo_from(z, dtype), U.halo_from(real_img, dtype)
+    fb, dzb = E.HaloBuf(n, s, s, c, dtype, U.DEV), E.HaloBuf(n, s, s, c, dtype, U.DEV)
+    inv = 1.0 / (n * s * s * c)
+    L.call("p2p_tanh_l1_fwd", dtype, n, s, s, c, C.byref(zb.view()), C.byref(rb.view()), C.byref(fb.view()), inv,
+           U.ptr(loss[3:]), U.stream())
+    zt = torch.tensor(z, dtype=F64, requires_grad=True)
+    fake_t = torch.tanh(zt)
+    l1 = (torch.tensor(real_img, dtype=F64) - fake_t).abs().mean()
+    assert U.rel_err(U.halo_to_np(fb), fake_t.detach().numpy()) < OUT_TOL[dtype]
+    assert abs(float(loss[3]) - float(l1)) < (1e-5 if dtype == L.F32 else 3e-3) * float(l1)
+    gsrc = E.DenseBuf(n, s, s, 8, U.tdt(dtype), U.DEV)
+    gsrc.t.copy_(U.dev(gd_src.reshape(-1, 8), U.tdt(dtype)))
+    lam = 100.0
+    L.call("p2p_tanh_l1_bwd", dtype, n, s, s, c, C.byref(fb.view()), C.byref(rb.view()), C.byref(gsrc.gsrc()), None,
+           lam * inv, C.byref(dzb.view()), U.stream())
+    (lam * l1 + (fake_t * torch.tensor(gd_src[..., :c], dtype=F64)).sum()).backward()
+    # sign(fake-real) flips where bf16 rounding of fake crosses real: compare where |fake-real| is not tiny
+    ok = np.abs(fake_t.detach().numpy() - real_img) > 1e-2
+    err = np.abs(U.halo_to_np(dzb) - zt.grad.numpy())[ok].max() / np.abs(zt.grad.numpy()).max()
+    assert err < (1e-5 if dtype == L.F32 else 1e-2)
+
+
+def test_adam_matches_keras_formulation():
+    rng = np.random.default_rng(15)
+    n = 10007
+    p, g = rng.normal(size=n).astype(np.float32), (rng.normal(size=n) * 1e-3).astype(np.float32)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    pd, gd, md, vd = U.dev(p), U.dev(g), U.dev(m), U.dev(v)
+    pr, mr, vr = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in (1, 2, 3):
+        L.call("p2p_adam_flat", U.ptr(pd), U.ptr(gd), U.ptr(md), U.ptr(vd), n, t, 2e-4, 0.5, 0.999, 1e-7, 1.0, U.stream())
+        pr, mr, vr = npr.keras_adam_step(pr, g.astype(np.float64), mr, vr, t)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), vr, rtol=1e-5)
+
+
+def test_dropout_mask_is_fair_and_reproducible():
+    n = 1 << 20
+    a = torch.empty(n, dtype=torch.uint8, device=U.DEV)
+    b = torch.empty(n, dtype=torch.uint8, device=U.DEV)
+    L.call("p2p_dropout_mask", U.ptr(a), n, 47, 1, U.stream())
+    L.call("p2p_dropout_mask", U.ptr(b), n, 47, 1, U.stream())
+    assert torch.equal(a, b) and int(a.max()) == 1
+    assert abs(float(a.float().mean()) - 0.5) < 5e-3
+    L.call("p2p_dropout_mask", U.ptr(b), n, 47, 2, U.stream())
+    assert abs(float((a == b).float().mean()) - 0.5) < 5e-3
+
+
+def test_bad_arguments_fail_loudly():
+    t = L.Tensor(0, 0, 0, 0)
+    with pytest.raises(L.P2PError):
+        L.call("p2p_igemm", L.OP_G, L.BF16, 1, 4, 4, 48, 64, C.byref(t), C.byref(t), None, 1, None, None)
+    with pytest.raises(L.P2PError):
+        L.call("p2p_conv_direct", 7, 2, L.F32, 1, 4, 4, 4, 4, C.byref(t), C.byref(t), None, None, None, None, None)
