@@ -102,6 +102,32 @@ def param_count(shapes):
 # --------------------------------------------------------------------------------------
 # layers
 # --------------------------------------------------------------------------------------
+_QUANT = None      # oracle-only: emulate the engine's bf16 storage points (straight-through rounding)
+
+
+class storage_dtype:
+    """Context manager: `with storage_dtype(torch.bfloat16): ...` rounds weights, conv outputs, block outputs and
+    images through that dtype at the points where the HIP engine stores them, gradients passing straight
+    through.  Used to check the bf16 throughput mode against the same graph with the same storage."""
+
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __enter__(self):
+        global _QUANT
+        self.prev, _QUANT = _QUANT, self.dt
+
+    def __exit__(self, *a):
+        global _QUANT
+        _QUANT = self.prev
+
+
+def _q(x):
+    if _QUANT is None:
+        return x
+    return x + (x.detach().to(_QUANT).to(x.dtype) - x.detach())
+
+
 def _nchw(x):
     return x.permute(0, 3, 1, 2)
 
@@ -113,19 +139,19 @@ def _nhwc(x):
 def conv4x4_s2(x, kernel):
     """Conv2D(f, 4, strides=2, padding='same', use_bias=False) (networks.py:10-16).
     TF SAME on an even input with k=4,s=2 pads (1,1); kernel HWIO."""
-    return _nhwc(F.conv2d(_nchw(x), kernel.permute(3, 2, 0, 1), stride=2, padding=1))
+    return _q(_nhwc(F.conv2d(_nchw(x), _q(kernel).permute(3, 2, 0, 1).contiguous(), stride=2, padding=1)))
 
 
 def convT4x4_s2(x, kernel):
     """Conv2DTranspose(f, 4, strides=2, padding='same', use_bias=False) (networks.py:26-27).
     Keras kernel (kh,kw,Cout,Cin); out[n,oh,ow,co] = sum_{oh=2ih+kh-1} x[n,ih,iw,ci] W[kh,kw,co,ci]."""
-    return _nhwc(F.conv_transpose2d(_nchw(x), kernel.permute(3, 2, 0, 1), stride=2, padding=1))
+    return _q(_nhwc(F.conv_transpose2d(_nchw(x), _q(kernel).permute(3, 2, 0, 1).contiguous(), stride=2, padding=1)))
 
 
 def conv4x4_s1_bias(x, kernel, bias):
     """Conv2D(f, 4, padding='same') with bias (networks.py:47-48,75-78). TF SAME pads 1 before, 2 after."""
     xp = F.pad(_nchw(x), (1, 2, 1, 2))
-    return _nhwc(F.conv2d(xp, kernel.permute(3, 2, 0, 1), bias=bias))
+    return _q(_nhwc(F.conv2d(xp, _q(kernel).permute(3, 2, 0, 1).contiguous(), bias=bias)))
 
 
 def instance_norm(x, gamma, beta):
@@ -149,7 +175,7 @@ def unet_downsample(x, p, name, apply_norm):
     x = conv4x4_s2(x, p[f"{name}.kernel"])
     if apply_norm:
         x = instance_norm(x, p[f"{name}.gamma"], p[f"{name}.beta"])
-    return leaky_relu(x)
+    return _q(leaky_relu(x))
 
 
 def unet_upsample(x, p, name, mask):
@@ -158,7 +184,7 @@ def unet_upsample(x, p, name, mask):
     x = instance_norm(x, p[f"{name}.gamma"], p[f"{name}.beta"])
     if mask is not None:
         x = dropout(x, mask)
-    return torch.relu(x)
+    return _q(torch.relu(x))
 
 
 def unet_generator(p, x, masks, last_activation):
@@ -175,7 +201,7 @@ def unet_generator(p, x, masks, last_activation):
         x = torch.cat([x, skip], dim=-1)
     x = conv4x4_s1_bias(x, p["last.kernel"], p["last.bias"])
     if last_activation == "tanh":
-        return torch.tanh(x)
+        return _q(torch.tanh(x))
     if last_activation == "softmax":
         return torch.softmax(x, dim=-1)
     if last_activation == "logits":          # oracle-only: pre-softmax values for the log-softmax CCE
@@ -186,7 +212,7 @@ def unet_generator(p, x, masks, last_activation):
 def patch_discriminator(p, target, source):
     """PatchDiscriminator forward (networks.py:45-48): concat [target, source] -> down(64, no IN) -> conv s1."""
     x = torch.cat([target, source], dim=-1)
-    x = leaky_relu(conv4x4_s2(x, p["down.kernel"]))
+    x = _q(leaky_relu(conv4x4_s2(x, p["down.kernel"])))
     return conv4x4_s1_bias(x, p["last.kernel"], p["last.bias"])
 
 
@@ -290,6 +316,7 @@ def train_step_rgba(Gp, Dp, source, real, masks, lambda_l1, lambda_hist=None, gl
     Both gradients are taken at the same (pre-update) weights; G's gradient flows through D.
     """
     Gl, Dl = _leaf(Gp), _leaf(Dp)
+    source, real = _q(source), _q(real)
     fake = unet_generator(Gl, source, masks, "tanh")                     # :67
     real_pred = patch_discriminator(Dl, real, source)                     # :69
     fake_pred = patch_discriminator(Dl, fake, source)                     # :70  (fake not detached)

@@ -39,7 +39,7 @@ def make_case(rng, n, lh, cg, cd, stride, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,stride", [(2, 4, 4, 64, 2), (1, 8, 8, 3, 2), (2, 5, 36, 4, 1), (3, 4, 64, 1, 1),
-                                                (2, 1, 5, 7, 2), (1, 3, 2, 2, 2)])
+                                                (2, 1, 5, 7, 2), (1, 3, 2, 2, 2), (2, 32, 32, 128, 2), (2, 8, 128, 512, 2)])
 def test_conv_direct(dtype, n, lh, cg, cd, stride):
     rng = np.random.default_rng(10)
     hi, lo, w = make_case(rng, n, lh, cg, cd, stride, dtype)
@@ -227,7 +227,7 @@ def test_adam_matches_keras_formulation():
         L.call("p2p_adam_flat", U.ptr(pd), U.ptr(gd), U.ptr(md), U.ptr(vd), n, t, 2e-4, 0.5, 0.999, 1e-7, 1.0, U.stream())
         pr, mr, vr = npr.keras_adam_step(pr, g.astype(np.float64), mr, vr, t)
     np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(vd.cpu().numpy(), vr, rtol=1e-5)
+    np.testing.assert_allclose(vd.cpu().numpy(), vr, rtol=5e-5)   # (1 - 0.999f) in f32, as keras does
 
 
 def test_dropout_mask_is_fair_and_reproducible():
