@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Pix2Pix side2side train images/s on synthetic 64x64x4 sprite batches (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One process per GPU; every rank runs the full train step (G fwd, D fwd x2, losses, both backward passes,
+gradient all-reduce over RCCL when N > 1, two Adam updates, weight-copy refresh) on its own shard of
+B images (weak scaling).  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from palette_and_histo_gan_amd import _lib as L          # noqa: E402
+from palette_and_histo_gan_amd import engine as E        # noqa: E402
+from palette_and_histo_gan_amd import flops as FL        # noqa: E402
+from palette_and_histo_gan_amd import parallel as PAR    # noqa: E402
+
+CONFIGS = {
+    # name: (model, per-GPU batch, img size, lambda_l1, lambda_hist, palette)
+    "c1": ("baseline", 4, 64, 100.0, None, None),
+    "c2": ("baseline", 256, 64, 100.0, None, None),
+    "c3": ("histogram", 256, 64, 30.0, 1.0, 24),
+    "c5": ("histogram", 256, 128, 30.0, 1.0, 24),
+}
+MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # TFLOP/s dense, MI355X_MICROARCH.md chip-level parameters
+
+
+def synthetic_batch(rank, B, S, palette):
+    from oracle import reference_graph as rg          # generator of the synthetic sprites only (data, not compute)
+    rng = np.random.default_rng([47, rank])
+    return rg.synthetic_rgba_batch(rng, B, S, palette_size=palette)
+
+
+def cpu_baseline(model, S, lambda_l1, lambda_hist, budget_s=20.0):
+    """The oracle (torch-CPU f32 restatement of the reference graph, TF 2.9.1 is not installable here) timed
+    on the host cores, on a bounded sample: B=4 batches (the reference's own batch size, configuration.py:24)."""
+    from oracle import reference_graph as rg
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(47)
+    Gp = rg.init_params(rg.generator_param_shapes(4, 4), rng, torch.float32)
+    Dp = rg.init_params(rg.discriminator_param_shapes(4), rng, torch.float32)
+    B = 4
+    src, tgt = rg.synthetic_rgba_batch(rng, B, S)
+    src, tgt = torch.tensor(src), torch.tensor(tgt)
+    gm, gv, dm, dv = (rg.zeros_like_params(Gp), rg.zeros_like_params(Gp), rg.zeros_like_params(Dp), rg.zeros_like_params(Dp))
+    steps, t0, t = 0, None, 0
+    while True:
+        masks = [torch.tensor(rng.integers(0, 2, size=s).astype(np.float32)) for s in rg.dropout_mask_shapes(B, S)]
+        out = rg.train_step_rgba(Gp, Dp, src, tgt, masks, lambda_l1, lambda_hist)
+        t += 1
+        Gp, gm, gv = rg.keras_adam(Gp, out["g_grads"], gm, gv, t)
+        Dp, dm, dv = rg.keras_adam(Dp, out["d_grads"], dm, dv, t)
+        if t0 is None:           # first step = warm-up
+            t0 = time.perf_counter()
+            continue
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 200:
+            break
+    return {"value": round(steps * B / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps of batch 4 at {S}x{S}, torch-CPU f32 restatement of the reference graph "
+                      f"({model} model), {el:.1f}s"}
+
+
+def kernel_profile(eng, run_step, n_steps=3):
+    """Per-entry-point device time with HIP events on the launch stream, one event pair per C-ABI call."""
+    records = []
+    orig = L.call
+
+    def timed(name, *args):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        orig(name, *args)
+        b.record()
+        records.append((name, args[:8], a, b))
+
+    L.call = timed
+    E.L.call = timed
+    try:
+        for _ in range(n_steps):
+            run_step()
+        torch.cuda.synchronize()
+    finally:
+        L.call = orig
+        E.L.call = orig
+    agg = {}
+    for name, args, a, b in records:
+        key = name
+        d = agg.setdefault(key, [0.0, 0])
+        d[0] += a.elapsed_time(b)
+        d[1] += 1
+    return {k: {"ms_per_step": v[0] / n_steps, "launches_per_step": v[1] / n_steps} for k, v in agg.items()}, records
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-mfma", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    comm = PAR.init_data_parallel(device) if world > 1 else None
+
+    model, B, S, lam_l1, lam_hist, palette = CONFIGS[args.config]
+    if args.batch:
+        B = args.batch
+    dtype = L.BF16 if args.dtype == "bf16" else L.F32
+    eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype, device=device, seed=47, use_mfma=not args.no_mfma)
+    src, tgt = synthetic_batch(rank, B, S, palette)
+    src_d = torch.as_tensor(src).to(device)
+    tgt_d = torch.as_tensor(tgt).to(device)
+    allreduce = comm.allreduce_grads if comm is not None else None
+
+    def run_step():
+        return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, allreduce=allreduce)
+
+    for _ in range(args.warmup):
+        run_step()
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = run_step()
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.max_scalar(elapsed)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    result = {
+        "metric": "train images/sec (64x64x4 sprites)" if S == 64 else f"train images/sec ({S}x{S}x4 sprites)",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.config}: {model} Pix2Pix train step, per-GPU batch {B}, {S}x{S} RGBA sprites, "
+                               f"lambda_l1={lam_l1}" + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
+                   "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}"},
+        "losses": [round(float(x), 5) for x in losses.cpu().numpy()],
+    }
+
+    if rank == 0:
+        flops_img = FL.train_step_flops_per_image(S, 4, 4)
+        result["conv_tflops"] = round(flops_img * value / 1e12, 2)
+        result["conv_mfma_frac_of_peak"] = round(flops_img * value / 1e12 / (MFMA_PEAK[args.dtype] * world), 4)
+        if not args.no_profile:
+            prof, records = kernel_profile(eng, run_step)
+            result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+            result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype, MFMA_PEAK[args.dtype])
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(model, S, lam_l1, lam_hist)
+        print(json.dumps(result), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,15 @@ int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd,
               const p2p_tensor* hi, const p2p_tensor* lo, const void* w,
               int splitk, float* slabs, void* stream);
 
+/* Edge-layer form of the same kernel (Cin 1..8, the 36/33-channel concat, Cout 1..4; networks.py:46-48,57,75-78):
+ * stride 1 or 2, any contraction width that fills whole 16-byte chunks (`cin_pad` = channels of the gathered
+ * view as padded in HBM and in `w`), output columns masked to `ncols` (launched in 32-wide tiles; `w_rows`, a
+ * multiple of 32 >= those tiles, = rows per tap slab of `w`), optional f32 bias[ncols] and LeakyReLU fused in
+ * the epilogue.  `w` is [16][w_rows][cin_pad] in `dtype` (p2p_weight_prep_pad). */
+int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                   const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
+                   int act, float alpha, void* stream);
+
 /* MFMA weight gradient of a stride-2 block: dw[16][Cg][Cd] (f32) = sum over pixels.  The pixel sum is
  * split over `msplit` workgroups per tile; partial slabs go to `workspace`
  * (p2p_wgemm_workspace_bytes) and are reduced deterministically. */
@@ -89,6 +98,15 @@ long long p2p_wgemm_workspace_bytes(int N, int LH, int LW, int Cg, int Cd, int m
 int p2p_wgemm(int dtype, int N, int LH, int LW, int Cg, int Cd,
               const p2p_tensor* hi, const p2p_tensor* lo, float* dw,
               int msplit, void* workspace, void* stream);
+
+/* Edge-layer form: stride 1 or 2, any Cg/Cd (store masked to the real counts); both views must have 16-byte
+ * pixels (pad the channel count) and a zero halo. */
+int p2p_wgemm_edge(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd,
+                   const p2p_tensor* hi, const p2p_tensor* lo, float* dw,
+                   int msplit, void* workspace, void* stream);
+
+/* out[c] = sum over all pixels of v[n,y,x,c] (f32): bias gradients of the stride-1 heads. */
+int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, void* stream);
 
 /* ---- InstanceNorm + activation + dropout (networks.py:18-19,29-34), fused ---------------------- */
 
@@ -111,6 +129,11 @@ int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C,
                      int act, float alpha, const unsigned char* mask,
                      const p2p_gsrc* g1, const p2p_gsrc* g2,
                      const p2p_tensor* draw, float* dgamma_part, float* dbeta_part, void* stream);
+
+/* Backward of a LeakyReLU that was fused into a conv epilogue (only its OUTPUT is stored):
+ * draw = (g1 + g2) * (act_out > 0 ? 1 : alpha). */
+int p2p_act_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* act_out, const p2p_gsrc* g1,
+                const p2p_gsrc* g2, float alpha, const p2p_tensor* draw, void* stream);
 
 /* out[c] = scale * sum_r part[r][c] (f32): batch reduction of dgamma/dbeta partials, loss partials. */
 int p2p_colsum(const float* part, int rows, int cols, float scale, float* out, void* stream);
@@ -141,6 +164,11 @@ int p2p_adam_flat(float* p, const float* g, float* m, float* v, long long n, int
 
 /* master f32 W[16][Cg][Cd] -> wn (dtype, same layout; may be null) and wt (dtype, [16][Cd][Cg]; may be null). */
 int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* wn, void* wt, void* stream);
+
+/* Padded variant for the edge layers: wn is [16][wn_rows][wn_cols], wt is [16][wt_rows][wt_cols]; entries
+ * outside the real [Cg][Cd] block are zero. */
+int p2p_weight_prep_pad(int dtype, const float* w, int Cg, int Cd, void* wn, int wn_rows, int wn_cols,
+                        void* wt, int wt_rows, int wt_cols, void* stream);
 
 /* dense f32 (or i32 if src_is_int) [N][H][W][C] host-layout batch -> view in `dtype` (dataset_utils.py:39-48 contract). */
 int p2p_pack_input(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,

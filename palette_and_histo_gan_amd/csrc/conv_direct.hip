@@ -132,6 +132,18 @@ __global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __re
     }
 }
 
+// out[d] = sum over all pixels of v[m][d]  (bias gradients of the two stride-1 heads, networks.py:47-48,75-78)
+extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && v && v->ptr && out, "p2p_view_colsum: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
+    if (e != hipSuccess) { p2p_set_error("p2p_view_colsum memset: %s", hipGetErrorString(e)); return (int)e; }
+    long long M = (long long)N * H * W;
+    int chunk = 4096;
+    P2P_DISPATCH_DTYPE(dtype, (view_colsum<T><<<dim3((unsigned)((M + chunk - 1) / chunk)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunk)));
+    return p2p_check_launch("p2p_view_colsum");
+}
+
 template <typename T>
 static int conv_direct_impl(int op, int stride, int N, int LH, int LW, int Cg, int Cd, TView hi, TView lo,
                             const void* w, const float* bias, float* dw, float* dbias, hipStream_t st) {

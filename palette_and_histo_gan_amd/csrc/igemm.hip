@@ -1,11 +1,12 @@
-// MFMA implicit GEMM for the 4x4 stride-2 encoder/decoder blocks (Conv2D / Conv2DTranspose forward and
-// their data gradients; reference call sites networks.py:10-16,26-27 and the tape gradients taken at
-// pix2pix_model.py:78).  Forms (include/p2pgan.h):
-//   op G: lo[m][d] = sum_{t=(kh,kw)} sum_g hi[n,2y+kh-1,2x+kw-1,g] * Wt[t][d][g]      (16 taps)
-//   op P: hi[n,2y+ph,2x+pw][g] = sum_{2x2 taps of phase (ph,pw)} sum_d lo[n,y+dy,x+dx,d] * Wn[t][g][d]
-// Both are "NT" GEMMs  C[m][n] = sum_k A[m][k] B[n][k]:  A rows are gathered 128-byte runs of one input
+// MFMA implicit GEMM for every 4x4 convolution of the step that maps pixels -> pixels: Conv2D /
+// Conv2DTranspose forward and their data gradients (reference call sites networks.py:10-16,26-27,46-48,75-78
+// and the tape gradients taken at pix2pix_model.py:78-79).  Forms (include/p2pgan.h), s = stride:
+//   op G: lo[m][d] = sum_{t=(kh,kw)} sum_g hi[n,s*y+kh-1,s*x+kw-1,g] * Wt[t][d][g]                (16 taps)
+//   op P, s=2: hi[n,2y+ph,2x+pw][g] = sum_{2x2 taps of phase (ph,pw)} sum_d lo[n,y+dy,x+dx,d] * Wn[t][g][d]
+//   op P, s=1: hi[n,y,x][g]         = sum_{t} sum_d lo[n,y+1-kh,x+1-kw,d] * Wn[t][g][d]           (16 taps)
+// All are "NT" GEMMs  C[m][n] = sum_k A[m][k] B[n][k]:  A rows are gathered 16-byte chunks of one input
 // pixel's channels (the zero halo around every image supplies the SAME padding, so no bounds checks),
-// B rows are 128-byte runs of one output channel's weights.
+// B rows are one output channel's weights.
 //
 // Tiling (CDNA4, wave64): 256 threads = 4 waves; block tile BM x BN, wave tile (TM x TN) 32x32 MFMA tiles,
 // K-block = 128 bytes per row (64 bf16 / 32 f32).  A and B tiles are staged global->LDS with
@@ -14,17 +15,25 @@
 // per-lane SOURCE address and again on the read.  Double-buffered: one barrier per K-block, the loads of
 // block k+1 are in flight while block k is multiplied.
 //   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.   f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact f32).
+// GEN = false: channels-per-tap bytes are a power of two (all encoder/decoder blocks) -> shifts only.
+// GEN = true : any multiple of 16 bytes per tap (edge layers: 8-channel images, the 36(+4)-channel concat, the
+//              33(+7)-channel indexed concat), plus bias / LeakyReLU / column mask in the epilogue.
 #include "p2p_common.hpp"
 
 struct IgemmArgs {
     const char* in; long long in_img; int in_row; int in_ld;      // gathered input view (element strides)
     char* out; long long out_img; int out_row; int out_ld;        // output view, splitk == 1
     float* slabs; long long slab_stride;                           // splitk > 1: f32 [ks][pixels][ncols]
-    const char* w;                                                  // [16][ncols][C] in T
+    const char* w;                                                  // [taps][ncols_pad][C] in T
+    const float* bias;                                              // GEN epilogue, may be null
     int M, lgLW, lgLH, LW, LH;
-    int C, lgCB;         // contraction channels per tap, log2(C*sizeof(T))
-    int ncols;           // output channels
-    int op, splitk, taps_per;
+    int C, lgCB, Cc;     // contraction channels per tap, log2(C*sizeof(T)) (pow2 path), 16-byte chunks per tap
+    int w_rows;          // rows of a weight tap slab (>= the launched column tiles)
+    int ncols;           // real output channels (stores are masked to col < ncols)
+    int mode;            // 0 = G, 1 = P stride 2 (4 phases), 2 = P stride 1
+    int si;              // input scale of op G (stride)
+    int splitk, taps_per;
+    int act; float alpha;
 };
 
 template <typename T> struct Frag;
@@ -44,7 +53,7 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, bool GEN>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -58,8 +67,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     const int ks = blockIdx.z % a.splitk, phase = blockIdx.z / a.splitk;
     const int ph = phase >> 1, pw = phase & 1;
     const int tap_begin = ks * a.taps_per;
-    const int CB = 1 << a.lgCB;                       // bytes per tap row
-    const int nkb = (a.taps_per << a.lgCB) >> 7;      // K-blocks of 128 bytes
+    const int CBbytes = GEN ? a.Cc * 16 : (1 << a.lgCB);          // bytes per tap row
+    const int nkb = (a.taps_per * CBbytes) >> 7;                  // K-blocks of 128 bytes
     const long long esz = sizeof(T);
 
     // ---- per-thread staging rows -------------------------------------------------------------------
@@ -72,8 +81,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         int x = m & (a.LW - 1);
         int y = (m >> a.lgLW) & (a.LH - 1);
         int n = m >> (a.lgLW + a.lgLH);
-        int by = a.op == P2P_OP_G ? 2 * y - 1 : y;
-        int bx = a.op == P2P_OP_G ? 2 * x - 1 : x;
+        int by = a.mode == 0 ? a.si * y - 1 : y;
+        int bx = a.mode == 0 ? a.si * x - 1 : x;
         abase[i] = ((long long)n * a.in_img + (long long)by * a.in_row + bx) * a.in_ld * esz;
         aq[i] = (lane & 7) ^ ((r >> 1) & 7);
     }
@@ -85,28 +94,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         bq[j] = (lane & 7) ^ ((r >> 1) & 7);
         bbase[j] = (long long)(n0 + r) * a.C * esz;
     }
-    const long long wtap = (long long)a.ncols * a.C * esz;   // bytes per weight tap slab
+    const long long wtap = (long long)a.w_rows * a.C * esz;   // bytes per weight tap slab
+
+    auto tap_geom = [&](int tl, int& dy, int& dx, int& widx) {
+        if (a.mode == 0) { dy = tl >> 2; dx = tl & 3; widx = tl; }
+        else if (a.mode == 1) {
+            int kh = (1 - ph) + 2 * (tl >> 1), kw = (1 - pw) + 2 * (tl & 1);
+            dy = (ph + 1 - kh) >> 1; dx = (pw + 1 - kw) >> 1; widx = kh * 4 + kw;
+        } else { dy = 1 - (tl >> 2); dx = 1 - (tl & 3); widx = tl; }
+    };
+    auto split_k = [&](int kb, int q, int& tl, int& cbyte) {
+        if (GEN) {
+            int kc = kb * 8 + q;
+            int tp = kc / a.Cc;
+            tl = tap_begin + tp;
+            cbyte = (kc - tp * a.Cc) << 4;
+        } else {
+            int kbyte = (kb << 7) + (q << 4);
+            tl = tap_begin + (kbyte >> a.lgCB);
+            cbyte = kbyte & (CBbytes - 1);
+        }
+    };
 
     auto stage = [&](int kb, char* buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            int kbyte = (kb << 7) + (aq[i] << 4);
-            int tl = tap_begin + (kbyte >> a.lgCB);
-            int cbyte = kbyte & (CB - 1);
-            int dy, dx;
-            if (a.op == P2P_OP_G) { dy = tl >> 2; dx = tl & 3; }
-            else { int kh = (1 - ph) + 2 * (tl >> 1), kw = (1 - pw) + 2 * (tl & 1); dy = (ph + 1 - kh) >> 1; dx = (pw + 1 - kw) >> 1; }
+            int tl, cbyte, dy, dx, widx;
+            split_k(kb, aq[i], tl, cbyte);
+            tap_geom(tl, dy, dx, widx);
             const char* src = a.in + abase[i] + ((long long)dy * a.in_row + dx) * a.in_ld * esz + cbyte;
             glds16(src, buf + (i * 4 + wave) * 1024);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            int kbyte = (kb << 7) + (bq[j] << 4);
-            int tl = tap_begin + (kbyte >> a.lgCB);
-            int cbyte = kbyte & (CB - 1);
-            int widx;
-            if (a.op == P2P_OP_G) widx = tl;
-            else widx = ((1 - ph) + 2 * (tl >> 1)) * 4 + (1 - pw) + 2 * (tl & 1);
+            int tl, cbyte, dy, dx, widx;
+            split_k(kb, bq[j], tl, cbyte);
+            tap_geom(tl, dy, dx, widx);
             const char* src = a.w + widx * wtap + bbase[j] + cbyte;
             glds16(src, buf + A_BYTES + (j * 4 + wave) * 1024);
         }
@@ -154,29 +177,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     }
 
     // ---- epilogue: D[row = m][col = n], col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -------------
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        bcol[j] = (GEN && a.bias && col < a.ncols) ? a.bias[col] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (m >= a.M) continue;
+            int x = m & (a.LW - 1);
+            int y = (m >> a.lgLW) & (a.LH - 1);
+            int n = m >> (a.lgLW + a.lgLH);
             long long pix;
-            if (a.op == P2P_OP_G) {
-                int x = m & (a.LW - 1);
-                int y = (m >> a.lgLW) & (a.LH - 1);
-                int n = m >> (a.lgLW + a.lgLH);
-                pix = (long long)n * a.out_img + (long long)y * a.out_row + x;
-            } else {
-                int x = m & (a.LW - 1);
-                int y = (m >> a.lgLW) & (a.LH - 1);
-                int n = m >> (a.lgLW + a.lgLH);
-                pix = (long long)n * a.out_img + (long long)(2 * y + ph) * a.out_row + (2 * x + pw);
-            }
+            if (a.mode == 1) pix = (long long)n * a.out_img + (long long)(2 * y + ph) * a.out_row + (2 * x + pw);
+            else pix = (long long)n * a.out_img + (long long)y * a.out_row + x;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-                if (a.splitk == 1) ((T*)a.out)[pix * a.out_ld + col] = from_f32<T>(acc[i][j][e]);
-                else a.slabs[(long long)ks * a.slab_stride + pix * a.out_ld + col] = acc[i][j][e];
+                if (GEN && col >= a.ncols) continue;
+                float v = acc[i][j][e];
+                if (a.splitk == 1) {
+                    if (GEN) {
+                        v += bcol[j];
+                        if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
+                    }
+                    ((T*)a.out)[pix * a.out_ld + col] = from_f32<T>(v);
+                } else {
+                    a.slabs[(long long)ks * a.slab_stride + pix * a.out_ld + col] = v;
+                }
             }
         }
     }
@@ -188,24 +220,71 @@ static int ilog2_exact(long long v) {
     return (1LL << l) == v ? l : -1;
 }
 
-template <typename T>
+template <typename T, bool GEN>
 static int igemm_launch(IgemmArgs& a, int phases, hipStream_t st) {
     dim3 block(256);
     unsigned gz = (unsigned)(phases * a.splitk);
-    if (a.ncols % 128 == 0) {
+    const int ctiles = (a.ncols + 31) / 32 * 32;      // launched columns (<= w_rows)
+    if (ctiles % 128 == 0) {
         constexpr int BM = 128, BN = 128;
-        dim3 grid((a.M + BM - 1) / BM, a.ncols / BN, gz);
-        igemm_kernel<T, 2, 2, 2, 2><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
-    } else if (a.ncols % 64 == 0) {
+        dim3 grid((a.M + BM - 1) / BM, ctiles / BN, gz);
+        igemm_kernel<T, 2, 2, 2, 2, GEN><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+    } else if (ctiles % 64 == 0) {
         constexpr int BM = 128, BN = 64;
-        dim3 grid((a.M + BM - 1) / BM, a.ncols / BN, gz);
-        igemm_kernel<T, 2, 2, 2, 1><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+        dim3 grid((a.M + BM - 1) / BM, ctiles / BN, gz);
+        igemm_kernel<T, 2, 2, 2, 1, GEN><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
     } else {
         constexpr int BM = 128, BN = 32;
-        dim3 grid((a.M + BM - 1) / BM, a.ncols / BN, gz);
-        igemm_kernel<T, 4, 1, 1, 1><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+        dim3 grid((a.M + BM - 1) / BM, ctiles / BN, gz);
+        igemm_kernel<T, 4, 1, 1, 1, GEN><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
     }
     return p2p_check_launch("p2p_igemm");
+}
+
+// Shared implementation.  C = channels of the gathered operand as laid out in `w` and read from the input
+// view (whole 16-byte chunks), w_rows = rows per weight tap slab (multiple of 32, >= the launched columns).
+static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, int C, int ncols, int w_rows,
+                        const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias, int act,
+                        float alpha, int splitk, float* slabs, void* stream) {
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    IgemmArgs a;
+    a.C = C; a.ncols = ncols; a.w_rows = w_rows;
+    a.bias = bias; a.act = act; a.alpha = alpha;
+    a.lgLW = ilog2_exact(LW);
+    a.lgLH = ilog2_exact(LH);
+    P2P_REQUIRE(a.lgLW >= 0 && a.lgLH >= 0, "p2p_igemm: LH=%d, LW=%d must be powers of two", LH, LW);
+    P2P_REQUIRE(((long long)C * esz) % 16 == 0, "p2p_igemm: contraction channels must fill whole 16-byte chunks (C=%d)", C);
+    P2P_REQUIRE(w_rows % 32 == 0 && ncols >= 1 && (ncols + 31) / 32 * 32 <= w_rows, "p2p_igemm: bad column counts %d/%d", ncols, w_rows);
+    P2P_REQUIRE((in->ld * esz) % 16 == 0 && ((uintptr_t)in->ptr % 16) == 0 && ((uintptr_t)w % 16) == 0,
+                "p2p_igemm: input pixels and weights must be 16-byte aligned");
+    a.Cc = C * esz / 16;
+    a.lgCB = ilog2_exact((long long)C * esz);
+    const bool pow2 = a.lgCB >= 6 && ncols == w_rows && !bias && act == P2P_ACT_NONE;
+    a.mode = op == P2P_OP_G ? 0 : (stride == 2 ? 1 : 2);
+    a.si = stride;
+    const int ntaps = a.mode == 1 ? 4 : 16;
+    P2P_REQUIRE(splitk >= 1 && ntaps % splitk == 0, "p2p_igemm: splitk=%d must divide %d", splitk, ntaps);
+    a.taps_per = ntaps / splitk;
+    P2P_REQUIRE(((long long)a.taps_per * C * esz) % 128 == 0, "p2p_igemm: K per split must be a multiple of 128 bytes");
+    P2P_REQUIRE(splitk == 1 || slabs, "p2p_igemm: splitk > 1 needs a slab workspace");
+    P2P_REQUIRE(splitk == 1 || (!bias && act == P2P_ACT_NONE), "p2p_igemm: bias/activation need splitk == 1");
+    a.in = (const char*)in->ptr; a.in_img = in->img_stride; a.in_row = in->row_stride; a.in_ld = in->ld;
+    a.out = (char*)out->ptr; a.out_img = out->img_stride; a.out_row = out->row_stride; a.out_ld = out->ld;
+    a.slabs = slabs;
+    const int os = a.mode == 1 ? 2 : 1;
+    const int OH = os * LH, OW = os * LW;
+    a.slab_stride = 0;
+    if (splitk > 1) {   // slabs are dense [pixels][ncols]
+        a.out_img = (long long)OH * OW; a.out_row = OW; a.out_ld = ncols;
+        a.slab_stride = (long long)N * OH * OW * ncols;
+    }
+    a.w = (const char*)w;
+    a.M = N * LH * LW; a.LW = LW; a.LH = LH;
+    a.splitk = splitk;
+    const int phases = a.mode == 1 ? 4 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (pow2) { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, false>(a, phases, st))); }
+    else { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, true>(a, phases, st))); }
 }
 
 extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
@@ -214,36 +293,18 @@ extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int C
     P2P_REQUIRE(N > 0 && LH > 0 && LW > 0, "p2p_igemm: bad shape");
     P2P_REQUIRE(Cg % 32 == 0 && Cd % 32 == 0 && Cg > 0 && Cd > 0, "p2p_igemm: Cg=%d, Cd=%d must be multiples of 32", Cg, Cd);
     P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && w, "p2p_igemm: null pointer");
-    const int esz = dtype == P2P_BF16 ? 2 : 4;
-    IgemmArgs a;
     const p2p_tensor* in = op == P2P_OP_G ? hi : lo;
     const p2p_tensor* out = op == P2P_OP_G ? lo : hi;
-    a.C = op == P2P_OP_G ? Cg : Cd;
-    a.ncols = op == P2P_OP_G ? Cd : Cg;
-    a.lgCB = ilog2_exact((long long)a.C * esz);
-    a.lgLW = ilog2_exact(LW);
-    a.lgLH = ilog2_exact(LH);
-    P2P_REQUIRE(a.lgCB >= 6, "p2p_igemm: contraction channels*elemsize must be a power of two >= 64 bytes (C=%d)", a.C);
-    P2P_REQUIRE(a.lgLW >= 0 && a.lgLH >= 0, "p2p_igemm: LH=%d, LW=%d must be powers of two", LH, LW);
-    P2P_REQUIRE((in->ld * esz) % 16 == 0 && ((uintptr_t)in->ptr % 16) == 0 && ((uintptr_t)w % 16) == 0,
-                "p2p_igemm: input pixels and weights must be 16-byte aligned");
-    const int ntaps = op == P2P_OP_G ? 16 : 4;
-    P2P_REQUIRE(splitk >= 1 && ntaps % splitk == 0, "p2p_igemm: splitk=%d must divide %d", splitk, ntaps);
-    a.taps_per = ntaps / splitk;
-    P2P_REQUIRE(((long long)a.taps_per << a.lgCB) % 128 == 0, "p2p_igemm: K per split must be a multiple of 128 bytes");
-    P2P_REQUIRE(splitk == 1 || slabs, "p2p_igemm: splitk > 1 needs a slab workspace");
-    a.in = (const char*)in->ptr; a.in_img = in->img_stride; a.in_row = in->row_stride; a.in_ld = in->ld;
-    a.out = (char*)out->ptr; a.out_img = out->img_stride; a.out_row = out->row_stride; a.out_ld = out->ld;
-    a.slabs = slabs;
-    const int OH = op == P2P_OP_G ? LH : 2 * LH, OW = op == P2P_OP_G ? LW : 2 * LW;
-    a.slab_stride = (long long)N * OH * OW * out->ld;
-    if (splitk > 1) {   // slabs are dense [pixels][ncols]
-        a.out_img = (long long)OH * OW; a.out_row = OW; a.out_ld = a.ncols;
-        a.slab_stride = (long long)N * OH * OW * a.ncols;
-    }
-    a.w = (const char*)w;
-    a.M = N * LH * LW; a.LW = LW; a.LH = LH;
-    a.op = op; a.splitk = splitk;
-    const int phases = op == P2P_OP_G ? 1 : 4;
-    P2P_DISPATCH_DTYPE(dtype, return igemm_launch<T>(a, phases, (hipStream_t)stream));
+    const int C = op == P2P_OP_G ? Cg : Cd, ncols = op == P2P_OP_G ? Cd : Cg;
+    return igemm_common(op, 2, dtype, N, LH, LW, C, ncols, ncols, in, out, w, nullptr, P2P_ACT_NONE, 0.f, splitk, slabs, stream);
+}
+
+extern "C" int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols,
+                              int w_rows, const p2p_tensor* in, const p2p_tensor* out, const void* w,
+                              const float* bias, int act, float alpha, void* stream) {
+    P2P_REQUIRE(op == P2P_OP_G || op == P2P_OP_P, "p2p_igemm_edge: op must be G or P");
+    P2P_REQUIRE(stride == 1 || stride == 2, "p2p_igemm_edge: stride must be 1 or 2");
+    P2P_REQUIRE(N > 0 && LH > 0 && LW > 0 && cin_pad > 0, "p2p_igemm_edge: bad shape");
+    P2P_REQUIRE(in && out && in->ptr && out->ptr && w, "p2p_igemm_edge: null pointer");
+    return igemm_common(op, stride, dtype, N, LH, LW, cin_pad, ncols, w_rows, in, out, w, bias, act, alpha, 1, nullptr, stream);
 }

@@ -151,6 +151,34 @@ __global__ void norm_act_bwd_kernel(int H, int W, int C, int CB, const T* __rest
     }
 }
 
+// Backward of a bare activation whose OUTPUT is stored (LeakyReLU fused into the conv epilogue of down1 / D.down,
+// networks.py:19,46,58): sign(out) == sign(pre-activation), so d(pre) = (g1 + g2) * (out > 0 ? 1 : alpha).
+template <typename T>
+__global__ void act_bwd_kernel(int N, int H, int W, int C, TView actv, GSrc g1, GSrc g2, float alpha, TView draw) {
+    long long total = (long long)N * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long p = i / C;
+        int x = (int)(p % W);
+        int y = (int)((p / W) % H);
+        int n = (int)(p / ((long long)W * H));
+        float a = to_f32(((const T*)actv.ptr)[actv.off(n, y, x) + c]);
+        float g = gsrc_load<T>(g1, p, c) + gsrc_load<T>(g2, p, c);
+        ((T*)draw.ptr)[draw.off(n, y, x) + c] = from_f32<T>(a > 0.f ? g : alpha * g);
+    }
+}
+
+extern "C" int p2p_act_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* act_out, const p2p_gsrc* g1,
+                           const p2p_gsrc* g2, float alpha, const p2p_tensor* draw, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && act_out && act_out->ptr && g1 && draw && draw->ptr, "p2p_act_bwd: bad args");
+    long long total = (long long)N * H * W * C;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    P2P_DISPATCH_DTYPE(dtype, (act_bwd_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
+                                  N, H, W, C, make_view(act_out), make_gsrc(g1), make_gsrc(g2), alpha, make_view(draw))));
+    return p2p_check_launch("p2p_act_bwd");
+}
+
 __global__ void colsum_kernel(const float* __restrict__ part, int rows, int cols, float scale, float* __restrict__ out) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;

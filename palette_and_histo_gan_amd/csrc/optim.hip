@@ -31,9 +31,12 @@ extern "C" int p2p_adam_flat(float* p, const float* g, float* m, float* v, long 
     return p2p_check_launch("p2p_adam_flat");
 }
 
-// wn[t][g][d] = T(w[t][g][d]);  wt[t][d][g] = T(w[t][g][d])   (32x32 LDS tile transpose per tap)
+// wn[t][g][d] = T(w[t][g][d]) for g < wn_rows, d < wn_cols;  wt[t][d][g] = T(w[t][g][d]) for d < wt_rows,
+// g < wt_cols; entries outside the real [Cg][Cd] block are written as zeros (channel padding of the edge
+// layers).  32x32 LDS tile transpose per tap.
 template <typename T>
-__global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, T* __restrict__ wn, T* __restrict__ wt) {
+__global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, T* __restrict__ wn, int wn_rows,
+                                   int wn_cols, T* __restrict__ wt, int wt_rows, int wt_cols) {
     __shared__ float tile[32][33];
     int t = blockIdx.z;
     int g0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
@@ -43,22 +46,31 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, 
         int g = g0 + r, d = d0 + tx;
         float val = (g < Cg && d < Cd) ? wp[(long long)g * Cd + d] : 0.f;
         tile[r][tx] = val;
-        if (wn && g < Cg && d < Cd) wn[(long long)t * Cg * Cd + (long long)g * Cd + d] = from_f32<T>(val);
+        if (wn && g < wn_rows && d < wn_cols) wn[((long long)t * wn_rows + g) * wn_cols + d] = from_f32<T>(val);
     }
     __syncthreads();
     if (wt) {
         for (int r = ty; r < 32; r += 8) {
             int d = d0 + r, g = g0 + tx;
-            if (g < Cg && d < Cd) wt[(long long)t * Cg * Cd + (long long)d * Cg + g] = from_f32<T>(tile[tx][r]);
+            if (d < wt_rows && g < wt_cols) wt[((long long)t * wt_rows + d) * wt_cols + g] = from_f32<T>(tile[tx][r]);
         }
     }
 }
 
-extern "C" int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* wn, void* wt, void* stream) {
+extern "C" int p2p_weight_prep_pad(int dtype, const float* w, int Cg, int Cd, void* wn, int wn_rows, int wn_cols,
+                                   void* wt, int wt_rows, int wt_cols, void* stream) {
     P2P_REQUIRE(w && Cg > 0 && Cd > 0 && (wn || wt), "p2p_weight_prep: bad args");
-    dim3 grid((Cd + 31) / 32, (Cg + 31) / 32, 16);
-    P2P_DISPATCH_DTYPE(dtype, (weight_prep_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(w, Cg, Cd, (T*)wn, (T*)wt)));
+    int gmax = Cg, dmax = Cd;
+    if (wn) { gmax = gmax > wn_rows ? gmax : wn_rows; dmax = dmax > wn_cols ? dmax : wn_cols; }
+    if (wt) { gmax = gmax > wt_cols ? gmax : wt_cols; dmax = dmax > wt_rows ? dmax : wt_rows; }
+    dim3 grid((dmax + 31) / 32, (gmax + 31) / 32, 16);
+    P2P_DISPATCH_DTYPE(dtype, (weight_prep_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(
+                                  w, Cg, Cd, (T*)wn, wn_rows, wn_cols, (T*)wt, wt_rows, wt_cols)));
     return p2p_check_launch("p2p_weight_prep");
+}
+
+extern "C" int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* wn, void* wt, void* stream) {
+    return p2p_weight_prep_pad(dtype, w, Cg, Cd, wn, Cg, Cd, wt, Cd, Cg, stream);
 }
 
 template <typename T>

@@ -1,12 +1,15 @@
-// MFMA weight gradient of the 4x4 stride-2 blocks (tape.gradient wrt the Conv2D / Conv2DTranspose kernels,
-// pix2pix_model.py:78-79 over networks.py:10-16,26-27):
-//     dW[t][g][d] = sum_{m=(n,y,x)} hi[n, 2y+kh-1, 2x+kw-1, g] * lo[n, y, x, d]          t = (kh,kw)
+// MFMA weight gradient of every 4x4 convolution (tape.gradient wrt the Conv2D / Conv2DTranspose kernels,
+// pix2pix_model.py:78-79 over networks.py:10-16,26-27,46-48,75-78), s = stride:
+//     dW[t][g][d] = sum_{m=(n,y,x)} hi[n, s*y+kh-1, s*x+kw-1, g] * lo[n, y, x, d]          t = (kh,kw)
 // A "TN" GEMM: both operands have the reduction index (the pixel) as their slow dimension.  Tiles are
 // staged [pixel][channel] exactly as they sit in HBM (global_load_lds_dwordx4, 16 B per lane); for bf16
 // the MFMA operand (8 consecutive pixels of one channel per lane) is produced by the CDNA4 transposing LDS
 // read ds_read_b64_tr_b16, for f32 (v_mfma_f32_32x32x2_f32, one pixel per lane) by a plain ds_read_b32.
-// One workgroup = one tap x BG x 128 output tile x one chunk of the pixel range; partial tiles go to f32
+// One workgroup = one tap x BG x BD output tile x one chunk of the pixel range; partial tiles go to f32
 // slabs [msplit][16][Cg][Cd] and are summed in a fixed order (deterministic, no float atomics).
+// Channel counts that are not tile multiples (edge layers: 4/8/36/33 channels, 1..4 output channels) are
+// handled by letting a tile row run past the pixel's channels into the following pixels' bytes (finite
+// values of the same buffer) and masking the store to g < Cg, d < Cd.
 #include "p2p_common.hpp"
 
 struct WgemmArgs {
@@ -14,7 +17,8 @@ struct WgemmArgs {
     const char* lo; long long lo_img; int lo_row; int lo_ld;
     float* part;            // [msplit][16][Cg][Cd]
     int M, LW, LH, lgLW, lgLH;
-    int Cg, Cd;
+    int Cg, Cd;             // real channel counts (store mask, output strides)
+    int stride;
     int chunk;              // pixels per workgroup (multiple of BK)
 };
 
@@ -33,46 +37,48 @@ __device__ __forceinline__ int swz_group(int row) {
     return (row / R) & (G - 1) & 3;
 }
 
-template <typename T, int BG, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void wgemm_kernel(WgemmArgs a) {
-    constexpr int BD = 128;
+template <typename T, int BG, int BD, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
+    constexpr int NW = WM * WN;
     constexpr int ESZ = sizeof(T);
     constexpr int BK = ESZ == 2 ? 64 : 32;          // pixels per stage
     constexpr int RBA = BG * ESZ, RBB = BD * ESZ;   // row bytes
     constexpr int A_BYTES = BK * RBA, B_BYTES = BK * RBB, STAGE = A_BYTES + B_BYTES;
-    constexpr int NIA = A_BYTES / 1024 / 4, NIB = B_BYTES / 1024 / 4;   // glds instructions per wave
+    constexpr int NIA = A_BYTES / 1024 / NW, NIB = B_BYTES / 1024 / NW;   // glds instructions per wave
     constexpr int LPA = RBA / 16, LPB = RBB / 16;   // lanes (16-byte chunks) per row
     static_assert(NIA >= 1 && NIB >= 1, "tile too small");
+    static_assert(WM * TM * 32 == BG && WN * TN * 32 == BD, "wave tiling must cover the block tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int gtiles = a.Cg / BG;
+    const int gtiles = (a.Cg + BG - 1) / BG;
     const int t = blockIdx.x / gtiles, g0 = (blockIdx.x % gtiles) * BG;
     const int d0 = blockIdx.y * BD;
     const int kh = t >> 2, kw = t & 3;
     const int mbeg = blockIdx.z * a.chunk;
     const int mend = min(mbeg + a.chunk, a.M);
     const int nst = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
+    const int s = a.stride;
 
-    auto stage = [&](int s, char* buf) {
-        const int mb = mbeg + s * BK;
+    auto stage = [&](int st, char* buf) {
+        const int mb = mbeg + st * BK;
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
-            int inst = i * 4 + wave;
+            int inst = i * NW + wave;
             int row = inst * (1024 / RBA) + lane / LPA;       // pixel within the stage
             int sl = lane % LPA;                               // physical 16-byte slot
             int lg = ((sl >> 2) ^ (ESZ == 2 ? swz_group<RBA>(row) : 0));
             int chunk = (lg << 2) | (sl & 3);
             int m = min(mb + row, a.M - 1);                    // clamped: the lo row of m >= M is a zero halo row
             int x = m & (a.LW - 1), y = (m >> a.lgLW) & (a.LH - 1), n = m >> (a.lgLW + a.lgLH);
-            const char* src = a.hi + (((long long)n * a.hi_img + (long long)(2 * y + kh - 1) * a.hi_row + (2 * x + kw - 1)) * a.hi_ld + g0) * ESZ + chunk * 16;
+            const char* src = a.hi + (((long long)n * a.hi_img + (long long)(s * y + kh - 1) * a.hi_row + (s * x + kw - 1)) * a.hi_ld + g0) * ESZ + chunk * 16;
             glds16w(src, buf + inst * 1024);
         }
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
-            int inst = i * 4 + wave;
+            int inst = i * NW + wave;
             int row = inst * (1024 / RBB) + lane / LPB;
             int sl = lane % LPB;
             int lg = ((sl >> 2) ^ (ESZ == 2 ? swz_group<RBB>(row) : 0));
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgemmArgs a) {
                 int x = m & (a.LW - 1), y = (m >> a.lgLW) & (a.LH - 1), n = m >> (a.lgLW + a.lgLH);
                 src = a.lo + (((long long)n * a.lo_img + (long long)y * a.lo_row + x) * a.lo_ld + d0) * ESZ + chunk * 16;
             } else {
-                src = a.lo + (((long long)(-1) * a.lo_row - 1) * a.lo_ld + d0) * ESZ + chunk * 16;   // halo pixel (0,-1,-1): zeros
+                src = a.lo + (((long long)(-1) * a.lo_row - 1) * a.lo_ld + d0) * ESZ + chunk * 16;   // halo row -1: zeros
             }
             glds16w(src, buf + A_BYTES + inst * 1024);
         }
@@ -98,11 +104,11 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgemmArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (nst > 0) stage(0, smem);
-    for (int s = 0; s < nst; ++s) {
+    for (int st = 0; st < nst; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        char* cur = smem + (s & 1) * STAGE;
-        if (s + 1 < nst) stage(s + 1, smem + ((s + 1) & 1) * STAGE);
+        char* cur = smem + (st & 1) * STAGE;
+        if (st + 1 < nst) stage(st + 1, smem + ((st + 1) & 1) * STAGE);
         if constexpr (ESZ == 2) {
             // lane l: 16-lane group grp, li = l&15, q = li>>2, p = li&3.  Read rd of k-step kk covers rows
             // kk*16 + 8*(grp>>1) + 4*rd + q, columns c0 + 16*(grp&1) + 4p .. +3 and returns to lane li the
@@ -172,10 +178,11 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             int g = g0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (g >= a.Cg) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 int d = d0 + (wn * TN + j) * 32 + (lane & 31);
-                outp[(long long)g * a.Cd + d] = acc[i][j][e];
+                if (d < a.Cd) outp[(long long)g * a.Cd + d] = acc[i][j][e];
             }
         }
 }
@@ -202,41 +209,49 @@ extern "C" long long p2p_wgemm_workspace_bytes(int N, int LH, int LW, int Cg, in
     return (long long)msplit * 16 * Cg * Cd * (long long)sizeof(float);
 }
 
+template <typename T, int BG, int BD, int WM, int WN, int TM, int TN>
+static void wgemm_go(WgemmArgs& a, int msplit, hipStream_t st) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int BK = ESZ == 2 ? 64 : 32;
+    dim3 grid(16 * ((a.Cg + BG - 1) / BG), (a.Cd + BD - 1) / BD, msplit);
+    wgemm_kernel<T, BG, BD, WM, WN, TM, TN><<<grid, dim3(WM * WN * 64), 2 * BK * (BG + BD) * ESZ, st>>>(a);
+}
+
 template <typename T>
 static int wgemm_launch(WgemmArgs& a, int msplit, hipStream_t st) {
     constexpr int ESZ = sizeof(T);
     constexpr int BK = ESZ == 2 ? 64 : 32;
     a.chunk = ((a.M + msplit - 1) / msplit + BK - 1) / BK * BK;
-    dim3 block(256);
-    if (a.Cg % 128 == 0) {
-        dim3 grid(16 * (a.Cg / 128), a.Cd / 128, msplit);
-        wgemm_kernel<T, 128, 2, 2, 2, 2><<<grid, block, 2 * BK * (128 + 128) * ESZ, st>>>(a);
-    } else if (a.Cg % 64 == 0) {
-        dim3 grid(16 * (a.Cg / 64), a.Cd / 128, msplit);
-        wgemm_kernel<T, 64, 2, 2, 1, 2><<<grid, block, 2 * BK * (64 + 128) * ESZ, st>>>(a);
+    const int cg = a.Cg, cd = a.Cd;
+    if (cd > 64) {
+        if (cg > 64) wgemm_go<T, 128, 128, 2, 2, 2, 2>(a, msplit, st);
+        else if (cg > 32) wgemm_go<T, 64, 128, 2, 2, 1, 2>(a, msplit, st);
+        else wgemm_go<T, 32, 128, 1, 4, 1, 1>(a, msplit, st);
+    } else if (cd > 32) {
+        if (cg > 32) wgemm_go<T, 64, 64, 2, 2, 1, 1>(a, msplit, st);
+        else wgemm_go<T, 32, 64, 1, 2, 1, 1>(a, msplit, st);
     } else {
-        dim3 grid(16 * (a.Cg / 32), a.Cd / 128, msplit);
-        wgemm_kernel<T, 32, 1, 4, 1, 1><<<grid, block, 2 * BK * (32 + 128) * ESZ, st>>>(a);
+        if (cg > 32) wgemm_go<T, 64, 32, 2, 1, 1, 1>(a, msplit, st);
+        else wgemm_go<T, 32, 32, 1, 1, 1, 1>(a, msplit, st);
     }
     return p2p_check_launch("p2p_wgemm");
 }
 
-extern "C" int p2p_wgemm(int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
-                         float* dw, int msplit, void* workspace, void* stream) {
-    P2P_REQUIRE(N > 0 && LH > 0 && LW > 0, "p2p_wgemm: bad shape");
-    P2P_REQUIRE(Cg % 32 == 0 && Cg > 0 && Cd % 128 == 0 && Cd > 0, "p2p_wgemm: need Cg %% 32 == 0 and Cd %% 128 == 0 (Cg=%d, Cd=%d)", Cg, Cd);
+static int wgemm_common(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
+                        const p2p_tensor* lo, float* dw, int msplit, void* workspace, void* stream) {
+    P2P_REQUIRE(N > 0 && LH > 0 && LW > 0 && Cg > 0 && Cd > 0, "p2p_wgemm: bad shape");
     P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && dw, "p2p_wgemm: null pointer");
     P2P_REQUIRE(msplit >= 1 && (msplit == 1 || workspace), "p2p_wgemm: msplit > 1 needs a workspace");
     const int esz = dtype == P2P_BF16 ? 2 : 4;
     P2P_REQUIRE((hi->ld * esz) % 16 == 0 && (lo->ld * esz) % 16 == 0 && ((uintptr_t)hi->ptr % 16) == 0 && ((uintptr_t)lo->ptr % 16) == 0,
-                "p2p_wgemm: pixels must be 16-byte aligned");
+                "p2p_wgemm: pixels must be 16-byte aligned (pad the channel count of the view)");
     WgemmArgs a;
     a.hi = (const char*)hi->ptr; a.hi_img = hi->img_stride; a.hi_row = hi->row_stride; a.hi_ld = hi->ld;
     a.lo = (const char*)lo->ptr; a.lo_img = lo->img_stride; a.lo_row = lo->row_stride; a.lo_ld = lo->ld;
     a.M = N * LH * LW; a.LW = LW; a.LH = LH;
     a.lgLW = ilog2_exact_w(LW); a.lgLH = ilog2_exact_w(LH);
     P2P_REQUIRE(a.lgLW >= 0 && a.lgLH >= 0, "p2p_wgemm: LH=%d, LW=%d must be powers of two", LH, LW);
-    a.Cg = Cg; a.Cd = Cd;
+    a.Cg = Cg; a.Cd = Cd; a.stride = stride;
     a.part = msplit == 1 ? dw : (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -250,4 +265,16 @@ extern "C" int p2p_wgemm(int dtype, int N, int LH, int LW, int Cg, int Cd, const
         return p2p_check_launch("p2p_wgemm reduce");
     }
     return 0;
+}
+
+extern "C" int p2p_wgemm(int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
+                         float* dw, int msplit, void* workspace, void* stream) {
+    P2P_REQUIRE(Cg % 32 == 0 && Cd % 32 == 0, "p2p_wgemm: need Cg %% 32 == 0 and Cd %% 32 == 0 (Cg=%d, Cd=%d); use p2p_wgemm_edge", Cg, Cd);
+    return wgemm_common(dtype, 2, N, LH, LW, Cg, Cd, hi, lo, dw, msplit, workspace, stream);
+}
+
+extern "C" int p2p_wgemm_edge(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
+                              const p2p_tensor* lo, float* dw, int msplit, void* workspace, void* stream) {
+    P2P_REQUIRE(stride == 1 || stride == 2, "p2p_wgemm_edge: stride must be 1 or 2");
+    return wgemm_common(dtype, stride, N, LH, LW, Cg, Cd, hi, lo, dw, msplit, workspace, stream);
 }

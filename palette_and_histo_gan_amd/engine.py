@@ -66,6 +66,15 @@ class DenseBuf:
                       self.n * self.h * self.w * self.c, self.c, coff)
 
 
+def pad8(c):
+    """channel count padded so that a pixel is a whole number of 16-byte chunks (bf16 and f32 alike)"""
+    return (c + 7) // 8 * 8
+
+
+def up32(c):
+    return (c + 31) // 32 * 32
+
+
 def _p(t, off_elems=0):
     return C.c_void_p(t.data_ptr() + off_elems * t.element_size())
 
@@ -140,6 +149,22 @@ def discriminator_param_shapes(in_ch):
     return OrderedDict([("down.kernel", (4, 4, 2 * in_ch, 64)), ("last.kernel", (4, 4, 64, 1)), ("last.bias", (1,))])
 
 
+class LayerW:
+    """Per-layer weight copies in the activation dtype, derived from the f32 master W[16][Cg][Cd] after every
+    Adam step (p2p_weight_prep_pad):
+      wt [16][up32(Cd)][hi_pad]  B operand of op G (conv forward / convT dgrad), contraction over the gathered
+                                 hi view whose pixels hold hi_pad channels in HBM;
+      wn [16][up32(Cg)][lo_pad]  B operand of op P (convT forward / conv dgrad), contraction over the lo view;
+      wd [16][Cg][Cd]            unpadded copy, only for the direct (non-MFMA) cross-check kernels.
+    Rows/columns beyond the real [Cg][Cd] block are zero."""
+
+    def __init__(self, cg, cd, hi_pad, lo_pad, need_g, need_p):
+        self.cg, self.cd, self.hi_pad, self.lo_pad = cg, cd, hi_pad, lo_pad
+        self.need_g, self.need_p = need_g, need_p
+        self.wt = self.wn = self.wd = None
+        self.main = cg % 32 == 0 and cd % 32 == 0 and hi_pad == cg and lo_pad == cd
+
+
 class Pix2PixEngine:
     """One generator + one discriminator + their optimizers on one GPU."""
 
@@ -155,7 +180,11 @@ class Pix2PixEngine:
         self.rng = np.random.default_rng(seed)
         self.seed, self.mask_counter = int(seed), 0
         self._init_params()
-        self.wcopies = {}           # (store id, name) -> dict(wn=tensor, wt=tensor)
+        self.c6_ch = pad8(UP_FILTERS[5] + in_ch)          # [up6 32 | source | zero pad]
+        self.src_ch = pad8(in_ch)
+        self.dcat_ch = pad8(2 * in_ch)
+        self.dz_ch = pad8(out_ch)
+        self.W = {}
         self._alloc_weight_copies()
         self.plans = {}
         self.lr, self.beta1, self.beta2, self.adam_eps = 2e-4, 0.5, 0.999, 1e-7   # pix2pix_model.py:28-29
@@ -177,42 +206,53 @@ class Pix2PixEngine:
                     vals[k] = np.zeros(s, np.float32)
             store.load(vals)
 
-    def _layers(self, store):
-        return [k[:-7] for k in store.shapes if k.endswith(".kernel")]
+    def _store(self, sid):
+        return self.G if sid == "G" else self.D
 
     def _alloc_weight_copies(self):
+        dev, tdt = self.device, self.tdt
         for sid, store in (("G", self.G), ("D", self.D)):
-            for name in self._layers(store):
-                kh, kw, cg, cd = store.shapes[name + ".kernel"]
-                n = 16 * cg * cd
-                ent = {"cg": cg, "cd": cd}
-                if self.dtype == L.F32:
-                    ent["wn"] = None           # the f32 master is its own native copy
-                else:
-                    ent["wn"] = torch.empty(n, dtype=self.tdt, device=self.device)
-                ent["wt"] = torch.empty(n, dtype=self.tdt, device=self.device) if (cg % 32 == 0 and cd % 32 == 0) else None
-                self.wcopies[(sid, name)] = ent
+            for key in store.shapes:
+                if not key.endswith(".kernel"):
+                    continue
+                name = key[:-7]
+                _, _, cg, cd = store.shapes[key]
+                hi_pad, lo_pad, need_p = cg, cd, True
+                if (sid, name) == ("G", "down1"):
+                    hi_pad, need_p = self.src_ch, False            # no data gradient wrt the source image
+                elif (sid, name) == ("G", "last"):
+                    hi_pad, lo_pad = self.c6_ch, self.dz_ch
+                elif (sid, name) == ("D", "down"):
+                    hi_pad = self.dcat_ch
+                elif (sid, name) == ("D", "last"):
+                    lo_pad = 8                                     # dlogits are stored with 8-channel pixels
+                lw = LayerW(cg, cd, hi_pad, lo_pad, True, need_p)
+                if self.use_mfma:
+                    lw.wt = torch.zeros(16 * up32(cd) * hi_pad, dtype=tdt, device=dev)
+                    if need_p and not (lw.main and self.dtype == L.F32):   # f32 main layers: the master IS wn
+                        lw.wn = torch.zeros(16 * up32(cg) * lo_pad, dtype=tdt, device=dev)
+                if (not self.use_mfma or not lw.main) and self.dtype != L.F32:
+                    lw.wd = torch.zeros(16 * cg * cd, dtype=tdt, device=dev)
+                self.W[(sid, name)] = lw
 
     def refresh_weight_copies(self):
-        """Re-derives the per-layer weight copies ([16][Cg][Cd] native and [16][Cd][Cg] transposed, in the
-        activation dtype) from the f32 masters; runs after every Adam step."""
-        for (sid, name), ent in self.wcopies.items():
-            store = self.G if sid == "G" else self.D
-            wn = _p(ent["wn"]) if ent["wn"] is not None else NULL
-            wt = _p(ent["wt"]) if ent["wt"] is not None else NULL
-            if ent["wn"] is None and ent["wt"] is None:
-                continue
-            L.call("p2p_weight_prep", self.dtype, store.p(name + ".kernel"), ent["cg"], ent["cd"], wn, wt, _stream())
+        """Re-derives the per-layer weight copies from the f32 masters; runs after every Adam step."""
+        for (sid, name), lw in self.W.items():
+            master = self._store(sid).p(name + ".kernel")
+            if lw.wt is not None or lw.wn is not None:
+                L.call("p2p_weight_prep_pad", self.dtype, master, lw.cg, lw.cd,
+                       _p(lw.wn) if lw.wn is not None else NULL, up32(lw.cg), lw.lo_pad,
+                       _p(lw.wt) if lw.wt is not None else NULL, up32(lw.cd), lw.hi_pad, _stream())
+            if lw.wd is not None:
+                L.call("p2p_weight_prep_pad", self.dtype, master, lw.cg, lw.cd, _p(lw.wd), lw.cg, lw.cd, NULL, 0, 0, _stream())
 
-    def wn(self, sid, name):
-        ent = self.wcopies[(sid, name)]
-        if ent["wn"] is None:
-            store = self.G if sid == "G" else self.D
-            return store.p(name + ".kernel")
-        return _p(ent["wn"])
+    def _wn(self, sid, name):
+        lw = self.W[(sid, name)]
+        return _p(lw.wn) if lw.wn is not None else self._store(sid).p(name + ".kernel")
 
-    def wt(self, sid, name):
-        return _p(self.wcopies[(sid, name)]["wt"])
+    def _wd(self, sid, name):
+        lw = self.W[(sid, name)]
+        return _p(lw.wd) if lw.wd is not None else self._store(sid).p(name + ".kernel")
 
     def set_params(self, g_values=None, d_values=None):
         if g_values is not None:
@@ -227,19 +267,22 @@ class Pix2PixEngine:
             return self.plans[B]
         S, dt, dev, tdt = self.S, self.dtype, self.device, self.tdt
         P = {"B": B}
-        # concat buffers c1..c6: [up_k output | skip]   (networks.py:92-94)
+        # concat buffers c1..c6: [up_k output | skip]   (networks.py:92-94); c6 = [up6 | source | zero pad]
         skips = list(reversed(DOWN_FILTERS[:-1])) + [self.in_ch]
         P["c"] = [None]
         for k in range(1, 7):
             res = S // 64 * (2 ** k)
-            P["c"].append(HaloBuf(B, res, res, UP_FILTERS[k - 1] + skips[k - 1], dt, dev))
+            ch = UP_FILTERS[k - 1] + skips[k - 1] if k < 6 else self.c6_ch
+            P["c"].append(HaloBuf(B, res, res, ch, dt, dev))
         r6 = S // 64
         P["a6"] = HaloBuf(B, r6, r6, 512, dt, dev)
+        P["src"] = HaloBuf(B, S, S, self.src_ch, dt, dev)        # down1's input, 16-byte pixels
         # raw conv outputs, stats, dropout masks, d(raw)
         P["rd"], P["ru"], P["sd"], P["su"], P["dd"], P["du"], P["mask"] = {}, {}, {}, {}, {}, {}, {}
         for i, f in enumerate(DOWN_FILTERS, start=1):
             res = S // (2 ** i)
-            P["rd"][i] = DenseBuf(B, res, res, f, tdt, dev)
+            if i > 1 or not self.use_mfma:
+                P["rd"][i] = DenseBuf(B, res, res, f, tdt, dev)
             P["dd"][i] = HaloBuf(B, res, res, f, dt, dev)
             if i > 1:
                 P["sd"][i] = torch.empty((B, f, 2), dtype=torch.float32, device=dev)
@@ -250,24 +293,25 @@ class Pix2PixEngine:
             P["su"][i] = torch.empty((B, f, 2), dtype=torch.float32, device=dev)
             if UP_DROPOUT[i - 1]:
                 P["mask"][i] = torch.empty((B * res * res, f), dtype=torch.uint8, device=dev)
-        # gradient sources: d(concat_k) for k=1..6, d(a_k) from the down path, d(a6)
+        # gradient sources: d(concat_k) for k=1..6, d(a_k) from the down path
         P["gc"] = [None] + [DenseBuf(B, P["c"][k].h, P["c"][k].w, P["c"][k].c, tdt, dev) for k in range(1, 7)]
         P["ga"] = {i: DenseBuf(B, S // 2 ** i, S // 2 ** i, DOWN_FILTERS[i - 1], tdt, dev) for i in range(1, 7)}
         P["part"] = torch.empty((2, B, 1024), dtype=torch.float32, device=dev)     # dgamma/dbeta partials
         # generator head
         P["z"] = DenseBuf(B, S, S, self.out_ch, tdt, dev)
-        P["dz"] = HaloBuf(B, S, S, self.out_ch, dt, dev)
+        P["dz"] = HaloBuf(B, S, S, self.dz_ch, dt, dev)
         # discriminator: images [0,B) = [real | source], [B,2B) = [fake | source]   (networks.py:45)
-        ic = self.in_ch
-        P["dcat"] = HaloBuf(2 * B, S, S, 2 * ic, dt, dev)
-        P["d_raw"] = DenseBuf(2 * B, S // 2, S // 2, 64, tdt, dev)
-        P["d_act"] = HaloBuf(2 * B, S // 2, S // 2, 64, dt, dev)
-        P["logits"] = DenseBuf(2 * B, S // 2, S // 2, 1, tdt, dev)
-        P["dld"] = HaloBuf(2 * B, S // 2, S // 2, 1, dt, dev)
-        P["dlg"] = HaloBuf(B, S // 2, S // 2, 1, dt, dev)
-        P["g_dact"] = DenseBuf(2 * B, S // 2, S // 2, 64, tdt, dev)
-        P["d_draw"] = HaloBuf(2 * B, S // 2, S // 2, 64, dt, dev)
-        P["g_dcat"] = DenseBuf(B, S, S, 2 * ic, tdt, dev)
+        h2 = S // 2
+        P["dcat"] = HaloBuf(2 * B, S, S, self.dcat_ch, dt, dev)
+        P["d_act"] = HaloBuf(2 * B, h2, h2, 64, dt, dev)
+        P["logits"] = DenseBuf(2 * B, h2, h2, 1, tdt, dev)
+        P["dld"] = HaloBuf(2 * B, h2, h2, 8, dt, dev)
+        P["dlg"] = HaloBuf(B, h2, h2, 8, dt, dev)
+        P["g_dact"] = DenseBuf(2 * B, h2, h2, 64, tdt, dev)
+        P["d_draw"] = HaloBuf(2 * B, h2, h2, 64, dt, dev)
+        P["g_dcat"] = DenseBuf(B, S, S, self.dcat_ch, tdt, dev)
+        if not self.use_mfma:
+            P["d_raw"] = DenseBuf(2 * B, h2, h2, 64, tdt, dev)
         # split-K / wgrad workspaces
         P["slabs"] = torch.empty(self._max_slab_elems(B), dtype=torch.float32, device=dev)
         P["wws"] = torch.empty(self._max_wgrad_ws(B) // 4 + 4, dtype=torch.float32, device=dev)
@@ -275,9 +319,6 @@ class Pix2PixEngine:
         return P
 
     # -- heuristics for the MFMA kernels --------------------------------------------------------------
-    def _mfma_ok(self, cg, cd, lh):
-        return self.use_mfma and cg % 32 == 0 and cd % 32 == 0 and (lh & (lh - 1)) == 0
-
     def _splitk(self, op, B, lh, cg, cd):
         ntaps = 16 if op == L.OP_G else 4
         ncols = cd if op == L.OP_G else cg
@@ -291,70 +332,93 @@ class Pix2PixEngine:
         return sk
 
     def _msplit(self, B, lh, cg, cd):
-        bg = 128 if cg % 128 == 0 else (64 if cg % 64 == 0 else 32)
-        tiles = 16 * (cg // bg) * (cd // 128)
+        bg = 128 if cg > 64 else (64 if cg > 32 else 32)
+        bd = 128 if cd > 64 else (64 if cd > 32 else 32)
+        tiles = 16 * ((cg + bg - 1) // bg) * ((cd + bd - 1) // bd)
         m = B * lh * lh
         ms = 1
         while tiles * ms < 512 and m // (ms * 2) >= 256:
             ms *= 2
         return ms
 
-    def _max_slab_elems(self, B):
-        S, best = self.S, 4
+    def _s2_layers(self):
+        """(cg, cd, lh factor) of every stride-2 block: lh = S // div for down, S // 64 * mul for up."""
+        out = []
         for i in range(2, 7):
-            lh = S // 2 ** i
-            cg, cd = DOWN_FILTERS[i - 2], DOWN_FILTERS[i - 1]
-            best = max(best, self._splitk(L.OP_G, B, lh, cg, cd) * B * lh * lh * cd)
-            best = max(best, self._splitk(L.OP_P, B, lh, cg, cd) * B * 4 * lh * lh * cg)
+            out.append((DOWN_FILTERS[i - 2], DOWN_FILTERS[i - 1], self.S // 2 ** i))
         cin = 512
         skips = list(reversed(DOWN_FILTERS[:-1])) + [self.in_ch]
         for i in range(1, 7):
-            lh = S // 64 * 2 ** (i - 1)
-            cg, cd = UP_FILTERS[i - 1], cin
-            best = max(best, self._splitk(L.OP_P, B, lh, cg, cd) * B * 4 * lh * lh * cg)
+            out.append((UP_FILTERS[i - 1], cin, self.S // 64 * 2 ** (i - 1)))
+            cin = UP_FILTERS[i - 1] + skips[i - 1]
+        return out
+
+    def _max_slab_elems(self, B):
+        best = 4
+        for cg, cd, lh in self._s2_layers():
             best = max(best, self._splitk(L.OP_G, B, lh, cg, cd) * B * lh * lh * cd)
-            cin = cg + skips[i - 1]
+            best = max(best, self._splitk(L.OP_P, B, lh, cg, cd) * B * 4 * lh * lh * cg)
         return best
 
     def _max_wgrad_ws(self, B):
         S, best = self.S, 16
-        for i in range(2, 7):
-            lh = S // 2 ** i
-            cg, cd = DOWN_FILTERS[i - 2], DOWN_FILTERS[i - 1]
+        layers = self._s2_layers() + [(self.in_ch, 64, S // 2), (self.c6_ch - (self.c6_ch - 32 - self.in_ch), self.out_ch, S)]
+        for cg, cd, lh in layers:
             best = max(best, self._msplit(B, lh, cg, cd) * 16 * cg * cd * 4)
-        cin = 512
-        skips = list(reversed(DOWN_FILTERS[:-1])) + [self.in_ch]
-        for i in range(1, 7):
-            lh = S // 64 * 2 ** (i - 1)
-            cg, cd = UP_FILTERS[i - 1], cin
-            best = max(best, self._msplit(B, lh, cg, cd) * 16 * cg * cd * 4)
-            cin = cg + skips[i - 1]
+        for cg, cd, lh in ((2 * self.in_ch, 64, S // 2), (64, 1, S // 2)):
+            best = max(best, self._msplit(2 * B, lh, cg, cd) * 16 * cg * cd * 4)
         return best
 
     # ------------------------------------------------------------------ kernel wrappers
-    def _conv(self, P, op, sid, name, N, lh, cg, cd, hi, lo, out_dense, stride=2, bias=None):
-        """op G or P.  Returns (raw_kind, nslabs) describing where the result went: the dense output buffer
-        in the activation dtype (1, 1) or f32 split-K slabs in P['slabs'] (2, nslabs)."""
-        if stride == 2 and bias is None and self._mfma_ok(cg, cd, lh):
+    def _conv(self, P, op, sid, name, N, lh, in_view, out_view, stride=2, ncols=None, bias=None, act=L.ACT_NONE,
+              tmp=None):
+        """op G (gathers the hi view, writes lo) or op P (gathers the lo view, writes hi).  Returns (raw_kind,
+        nslabs): the result is in the output view in the activation dtype (1, 1) or in the f32 split-K slabs
+        P['slabs'] (2, nslabs).  `ncols` limits op P to the first ncols output channels."""
+        lw = self.W[(sid, name)]
+        cg, cd = lw.cg, lw.cd
+        hi, lo = (in_view, out_view) if op == L.OP_G else (out_view, in_view)
+        if self.use_mfma and lw.main and stride == 2 and bias is None and act == L.ACT_NONE and ncols is None:
             sk = self._splitk(op, N, lh, cg, cd)
-            w = self.wt(sid, name) if op == L.OP_G else self.wn(sid, name)
+            w = _p(lw.wt) if op == L.OP_G else self._wn(sid, name)
             L.call("p2p_igemm", op, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), w, sk,
                    _p(P["slabs"]) if sk > 1 else NULL, _stream())
             return (1, 1) if sk == 1 else (2, sk)
-        L.call("p2p_conv_direct", op, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo),
-               self.wn(sid, name), bias if bias is not None else NULL, NULL, NULL, _stream())
+        if self.use_mfma:
+            if op == L.OP_G:
+                cin_pad, nc, rows, w = lw.hi_pad, cd, up32(cd), _p(lw.wt)
+            else:
+                cin_pad, nc, rows, w = lw.lo_pad, (ncols or cg), up32(cg), self._wn(sid, name)
+            L.call("p2p_igemm_edge", op, stride, self.dtype, N, lh, lh, cin_pad, nc, rows, C.byref(in_view),
+                   C.byref(out_view), w, bias if bias is not None else NULL, act, LEAKY_ALPHA, _stream())
+            return (1, 1)
+        # direct (non-MFMA) cross-check path
+        if act != L.ACT_NONE:
+            L.call("p2p_conv_direct", op, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(tmp.view()),
+                   self._wd(sid, name), bias if bias is not None else NULL, NULL, NULL, _stream())
+            L.call("p2p_norm_act_fwd", self.dtype, N, lh, lh, cd, tmp.ptr(), 1, 1, 0, NULL, NULL, IN_EPS, act,
+                   LEAKY_ALPHA, NULL, C.byref(out_view), NULL, NULL, _stream())
+        else:
+            L.call("p2p_conv_direct", op, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo),
+                   self._wd(sid, name), bias if bias is not None else NULL, NULL, NULL, _stream())
         return (1, 1)
 
-    def _wgrad(self, P, sid, name, N, lh, cg, cd, hi, lo, stride=2, dbias=None):
-        store = self.G if sid == "G" else self.D
-        dw = store.g(name + ".kernel")
-        if stride == 2 and dbias is None and self._mfma_ok(cg, cd, lh) and cd % 128 == 0:
-            ms = self._msplit(N, lh, cg, cd)
-            L.call("p2p_wgemm", self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), dw, ms,
-                   _p(P["wws"]) if ms > 1 else NULL, _stream())
-        else:
+    def _wgrad(self, P, sid, name, N, lh, hi, lo, stride=2, dbias=None):
+        lw = self.W[(sid, name)]
+        cg, cd = lw.cg, lw.cd
+        dw = self._store(sid).g(name + ".kernel")
+        if not self.use_mfma:
             L.call("p2p_conv_direct", L.OP_W, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo),
                    NULL, NULL, dw, dbias if dbias is not None else NULL, _stream())
+            return
+        ms = self._msplit(N, lh, cg, cd)
+        ws = _p(P["wws"]) if ms > 1 else NULL
+        if lw.main and stride == 2:
+            L.call("p2p_wgemm", self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), dw, ms, ws, _stream())
+        else:
+            L.call("p2p_wgemm_edge", self.dtype, stride, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), dw, ms, ws, _stream())
+        if dbias is not None:
+            L.call("p2p_view_colsum", self.dtype, N, lh, lh, cd, C.byref(lo), dbias, _stream())
 
     def _norm_fwd(self, P, N, res, c, raw_buf, rk, gamma, beta, act, mask, out_view, stats):
         raw_kind, nslabs = rk
@@ -371,19 +435,19 @@ class Pix2PixEngine:
             return buf.gsrc(coff=coff, kind=1)
         return L.GSrc(P["slabs"].data_ptr(), 2, rk[1], buf.n * buf.h * buf.w * buf.c, buf.c, coff)
 
-    def _norm_bwd(self, P, store_name, N, res, c, raw_buf, stats, act, mask, g1, g2, draw_view, norm=True):
+    def _norm_bwd(self, P, name, N, res, c, raw_buf, stats, act, mask, g1, g2, draw_view):
         part = P["part"]
-        gam = self.G.p(store_name + ".gamma") if norm else NULL
-        bet = self.G.p(store_name + ".beta") if norm else NULL
-        L.call("p2p_norm_act_bwd", self.dtype, N, res, res, c, raw_buf.ptr(), _p(stats) if norm else NULL, gam, bet,
-               act, LEAKY_ALPHA, _p(mask) if mask is not None else NULL, C.byref(g1),
-               C.byref(g2) if g2 is not None else None, C.byref(draw_view),
-               _p(part[1]) if norm else NULL, _p(part[0]) if norm else NULL, _stream())
-        if norm:
-            # batch reduction of the per-image partials (dense [N][c] at the start of each scratch plane)
-            # into the flat gradient buffer: dgamma/dbeta sum over batch AND space
-            L.call("p2p_colsum", _p(part[1]), N, c, 1.0, self.G.g(store_name + ".gamma"), _stream())
-            L.call("p2p_colsum", _p(part[0]), N, c, 1.0, self.G.g(store_name + ".beta"), _stream())
+        L.call("p2p_norm_act_bwd", self.dtype, N, res, res, c, raw_buf.ptr(), _p(stats), self.G.p(name + ".gamma"),
+               self.G.p(name + ".beta"), act, LEAKY_ALPHA, _p(mask) if mask is not None else NULL, C.byref(g1),
+               C.byref(g2) if g2 is not None else None, C.byref(draw_view), _p(part[1]), _p(part[0]), _stream())
+        # batch reduction of the per-image partials (dense [N][c] at the start of each scratch plane) into the
+        # flat gradient buffer: dgamma/dbeta sum over batch AND space
+        L.call("p2p_colsum", _p(part[1]), N, c, 1.0, self.G.g(name + ".gamma"), _stream())
+        L.call("p2p_colsum", _p(part[0]), N, c, 1.0, self.G.g(name + ".beta"), _stream())
+
+    def _act_bwd(self, N, res, c, act_view, g1, g2, draw_view):
+        L.call("p2p_act_bwd", self.dtype, N, res, res, c, C.byref(act_view), C.byref(g1),
+               C.byref(g2) if g2 is not None else None, LEAKY_ALPHA, C.byref(draw_view), _stream())
 
     # ------------------------------------------------------------------ forward
     def _to_device(self, arr, c, B, is_int=False):
@@ -399,30 +463,33 @@ class Pix2PixEngine:
         is_int = t.dtype == torch.int32
         L.call("p2p_pack_input", self.dtype, P["B"], self.S, self.S, c, _p(t), 1 if is_int else 0, C.byref(view), _stream())
 
+    def _pack_source(self, P, src_t):
+        ic = self.in_ch
+        self._pack(P, src_t, P["src"].view(), ic)                               # down1 input
+        self._pack(P, src_t, P["c"][6].view(coff=UP_FILTERS[5]), ic)            # last skip = raw input (networks.py:92)
+
     def generator_forward(self, P, masks=None):
         """UnetGenerator forward up to the pre-activation head output z (networks.py:80-98)."""
         B, S = P["B"], self.S
         c = P["c"]
-        # down path
-        src_view, cin = c[6].view(coff=UP_FILTERS[5]), self.in_ch
         P["rk_d"], P["rk_u"] = {}, {}
+        # down path: Conv2D s2 -> [InstanceNorm] -> LeakyReLU, output written into its slice of the concat buffer
+        src_view = P["src"].view()
         for i, f in enumerate(DOWN_FILTERS, start=1):
             res = S // 2 ** i
-            rk = self._conv(P, L.OP_G, "G", f"down{i}", B, res, cin, f, src_view, P["rd"][i].view(), P["rd"][i])
-            P["rk_d"][i] = rk
             out_view = P["a6"].view() if i == 6 else c[6 - i].view(coff=UP_FILTERS[5 - i])
-            if i == 1:
-                self._norm_fwd(P, B, res, f, P["rd"][i], rk, None, None, L.ACT_LEAKY, None, out_view, None)
+            if i == 1:      # no norm (networks.py:58): LeakyReLU fused in the conv epilogue
+                self._conv(P, L.OP_G, "G", "down1", B, res, src_view, out_view, act=L.ACT_LEAKY, tmp=P["rd"].get(1))
             else:
+                rk = self._conv(P, L.OP_G, "G", f"down{i}", B, res, src_view, P["rd"][i].view())
                 self._norm_fwd(P, B, res, f, P["rd"][i], rk, self.G.p(f"down{i}.gamma"), self.G.p(f"down{i}.beta"),
                                L.ACT_LEAKY, None, out_view, P["sd"][i])
-            src_view, cin = out_view, f
-        # up path
-        lo_view, cin = P["a6"].view(), 512
+            src_view = out_view
+        # up path: Conv2DTranspose s2 -> InstanceNorm -> [Dropout] -> ReLU -> first slice of the concat buffer
+        lo_view = P["a6"].view()
         for i, f in enumerate(UP_FILTERS, start=1):
             lh = S // 64 * 2 ** (i - 1)
-            rk = self._conv(P, L.OP_P, "G", f"up{i}", B, lh, f, cin, P["ru"][i].view(), lo_view, P["ru"][i])
-            P["rk_u"][i] = rk
+            rk = self._conv(P, L.OP_P, "G", f"up{i}", B, lh, lo_view, P["ru"][i].view())
             mask = None
             if UP_DROPOUT[i - 1]:
                 mask = P["mask"][i]
@@ -433,18 +500,29 @@ class Pix2PixEngine:
                     L.call("p2p_dropout_mask", _p(mask), mask.numel(), self.seed, self.mask_counter, _stream())
             self._norm_fwd(P, B, 2 * lh, f, P["ru"][i], rk, self.G.p(f"up{i}.gamma"), self.G.p(f"up{i}.beta"),
                            L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i])
-            lo_view, cin = c[i].view(), c[i].c
+            lo_view = c[i].view()
         # head: Conv2D(out, 4, stride 1, SAME, bias) (networks.py:75-78)
-        self._conv(P, L.OP_G, "G", "last", B, S, cin, self.out_ch, c[6].view(), P["z"].view(), P["z"], stride=1,
-                   bias=self.G.p("last.bias"))
+        self._conv(P, L.OP_G, "G", "last", B, S, c[6].view(), P["z"].view(), stride=1, bias=self.G.p("last.bias"))
 
     def discriminator_forward(self, P, N2):
         """PatchDiscriminator on the first N2 images of dcat (networks.py:45-48)."""
-        S, ic = self.S, self.in_ch
-        self._conv(P, L.OP_G, "D", "down", N2, S // 2, 2 * ic, 64, P["dcat"].view(), P["d_raw"].view(), P["d_raw"])
-        self._norm_fwd(P, N2, S // 2, 64, P["d_raw"], (1, 1), None, None, L.ACT_LEAKY, None, P["d_act"].view(), None)
-        self._conv(P, L.OP_G, "D", "last", N2, S // 2, 64, 1, P["d_act"].view(), P["logits"].view(), P["logits"],
-                   stride=1, bias=self.D.p("last.bias"))
+        h2 = self.S // 2
+        self._conv(P, L.OP_G, "D", "down", N2, h2, P["dcat"].view(), P["d_act"].view(), act=L.ACT_LEAKY, tmp=P.get("d_raw"))
+        self._conv(P, L.OP_G, "D", "last", N2, h2, P["d_act"].view(), P["logits"].view(), stride=1, bias=self.D.p("last.bias"))
+
+    def discriminator_backward(self, P, B):
+        """d(D loss)/d(D weights) (pix2pix_model.py:79), then the generator's adversarial gradient through D with the
+        same (pre-update) D weights down to d(fake) in g_dcat[..., :in_ch] (pix2pix_model.py:78)."""
+        S, ic, h2 = self.S, self.in_ch, self.S // 2
+        self._wgrad(P, "D", "last", 2 * B, h2, P["d_act"].view(), P["dld"].view(), stride=1, dbias=self.D.g("last.bias"))
+        self._conv(P, L.OP_P, "D", "last", 2 * B, h2, P["dld"].view(), P["g_dact"].view(), stride=1)
+        self._act_bwd(2 * B, h2, 64, P["d_act"].view(), P["g_dact"].gsrc(), None, P["d_draw"].view())
+        self._wgrad(P, "D", "down", 2 * B, h2, P["dcat"].view(), P["d_draw"].view())
+        if P.get("skip_g_through_d"):
+            return
+        self._conv(P, L.OP_P, "D", "last", B, h2, P["dlg"].view(), P["g_dact"].view(), stride=1)
+        self._act_bwd(B, h2, 64, P["d_act"].view(n0=B), P["g_dact"].gsrc(), None, P["d_draw"].view())
+        self._conv(P, L.OP_P, "D", "down", B, h2, P["d_draw"].view(), P["g_dcat"].view(), ncols=ic)
 
     # ------------------------------------------------------------------ train step (RGBA models)
     def train_step_rgba(self, source, real, lambda_l1, lambda_hist=None, masks=None, global_batch=None,
@@ -455,9 +533,8 @@ class Pix2PixEngine:
         P = self.plan(B)
         S, ic = self.S, self.in_ch
         Bg = global_batch or B
-        c = P["c"]
         src_t, real_t = self._to_device(source, ic, B), self._to_device(real, ic, B)
-        self._pack(P, src_t, c[6].view(coff=UP_FILTERS[5]), ic)
+        self._pack_source(P, src_t)
         self._pack(P, src_t, P["dcat"].view(coff=ic), ic)
         self._pack(P, src_t, P["dcat"].view(coff=ic, n0=B), ic)
         self._pack(P, real_t, P["dcat"].view(coff=0), ic)
@@ -467,25 +544,14 @@ class Pix2PixEngine:
         L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
                C.byref(fake_view), inv_l1, _p(self.losses, 3), _stream())
         self.discriminator_forward(P, 2 * B)
-        inv_bce = 1.0 / (Bg * (S // 2) * (S // 2))
-        L.call("p2p_bce_logits", self.dtype, 2 * B, B, S // 2, S // 2, C.byref(P["logits"].view()), inv_bce,
+        h2 = S // 2
+        inv_bce = 1.0 / (Bg * h2 * h2)
+        L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), inv_bce,
                C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.losses, 0), _stream())
         g_extra = None
         if lambda_hist is not None:
             g_extra = self._histogram_loss(P, B, Bg, lambda_hist, allreduce)
-        # ---- discriminator gradients (pix2pix_model.py:79)
-        h2 = S // 2
-        self._wgrad(P, "D", "last", 2 * B, h2, 64, 1, P["d_act"].view(), P["dld"].view(), stride=1,
-                    dbias=self.D.g("last.bias"))
-        self._conv(P, L.OP_P, "D", "last", 2 * B, h2, 64, 1, P["g_dact"].view(), P["dld"].view(), P["g_dact"], stride=1)
-        L.call("p2p_norm_act_bwd", self.dtype, 2 * B, h2, h2, 64, P["d_raw"].ptr(), NULL, NULL, NULL, L.ACT_LEAKY,
-               LEAKY_ALPHA, NULL, C.byref(P["g_dact"].gsrc()), None, C.byref(P["d_draw"].view()), NULL, NULL, _stream())
-        self._wgrad(P, "D", "down", 2 * B, h2, 2 * ic, 64, P["dcat"].view(), P["d_draw"].view())
-        # ---- generator gradients through D (pix2pix_model.py:78; D weights pre-update)
-        self._conv(P, L.OP_P, "D", "last", B, h2, 64, 1, P["g_dact"].view(), P["dlg"].view(), P["g_dact"], stride=1)
-        L.call("p2p_norm_act_bwd", self.dtype, B, h2, h2, 64, P["d_raw"].ptr(n0=B), NULL, NULL, NULL, L.ACT_LEAKY,
-               LEAKY_ALPHA, NULL, C.byref(P["g_dact"].gsrc()), None, C.byref(P["d_draw"].view()), NULL, NULL, _stream())
-        self._conv(P, L.OP_P, "D", "down", B, h2, 2 * ic, 64, P["g_dcat"].view(), P["d_draw"].view(), P["g_dcat"])
+        self.discriminator_backward(P, B)
         L.call("p2p_tanh_l1_bwd", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), C.byref(real_view),
                C.byref(P["g_dcat"].gsrc()), C.byref(g_extra) if g_extra is not None else None,
                float(lambda_l1) * inv_l1, C.byref(P["dz"].view()), _stream())
@@ -496,34 +562,28 @@ class Pix2PixEngine:
         """Backward of UnetGenerator from dz (the gradient at the head's pre-activation)."""
         B, S = P["B"], self.S
         c, gc, ga = P["c"], P["gc"], P["ga"]
-        cin6 = c[6].c
-        self._wgrad(P, "G", "last", B, S, cin6, self.out_ch, c[6].view(), P["dz"].view(), stride=1,
-                    dbias=self.G.g("last.bias"))
-        self._conv(P, L.OP_P, "G", "last", B, S, cin6, self.out_ch, gc[6].view(), P["dz"].view(), gc[6], stride=1)
+        self._wgrad(P, "G", "last", B, S, c[6].view(), P["dz"].view(), stride=1, dbias=self.G.g("last.bias"))
+        # d(concat6): only the 32 channels of up6's output are needed (the source image has no gradient)
+        self._conv(P, L.OP_P, "G", "last", B, S, P["dz"].view(), gc[6].view(), stride=1, ncols=UP_FILTERS[5])
         rk_gc = {6: (1, 1)}
         # up path, last to first
         for i in range(6, 0, -1):
             f = UP_FILTERS[i - 1]
             lh = S // 64 * 2 ** (i - 1)
             lo_buf = c[i - 1] if i > 1 else P["a6"]
-            cin = lo_buf.c
-            mask = P["mask"].get(i)
-            self._norm_bwd(P, f"up{i}", B, 2 * lh, f, P["ru"][i], P["su"][i], L.ACT_RELU, mask,
+            self._norm_bwd(P, f"up{i}", B, 2 * lh, f, P["ru"][i], P["su"][i], L.ACT_RELU, P["mask"].get(i),
                            self._gs(P, gc[i], rk_gc[i], 0), None, P["du"][i].view())
-            self._wgrad(P, "G", f"up{i}", B, lh, f, cin, P["du"][i].view(), lo_buf.view())
+            self._wgrad(P, "G", f"up{i}", B, lh, P["du"][i].view(), lo_buf.view())
+            out_buf = gc[i - 1] if i > 1 else ga[6]
+            rk = self._conv(P, L.OP_G, "G", f"up{i}", B, lh, P["du"][i].view(), out_buf.view())
+            rk = self._materialise(P, out_buf, rk)
             if i > 1:
-                # d(concat_{i-1}) must outlive the split-K slabs: finalise into the dense buffer when needed
-                rk = self._conv(P, L.OP_G, "G", f"up{i}", B, lh, f, cin, P["du"][i].view(), gc[i - 1].view(), gc[i - 1])
-                rk_gc[i - 1] = self._materialise(P, gc[i - 1], rk)
-            else:
-                rk = self._conv(P, L.OP_G, "G", "up1", B, lh, f, cin, P["du"][1].view(), ga[6].view(), ga[6])
-                rk_ga6 = self._materialise(P, ga[6], rk)
+                rk_gc[i - 1] = rk
         # down path, last to first
-        g_from_down = self._gs(P, ga[6], rk_ga6, 0)
+        g_from_down = ga[6].gsrc()
         for i in range(6, 0, -1):
             f = DOWN_FILTERS[i - 1]
             res = S // 2 ** i
-            cin = DOWN_FILTERS[i - 2] if i > 1 else self.in_ch
             if i == 6:
                 g1, g2 = g_from_down, None
             else:
@@ -532,14 +592,15 @@ class Pix2PixEngine:
             if i > 1:
                 self._norm_bwd(P, f"down{i}", B, res, f, P["rd"][i], P["sd"][i], L.ACT_LEAKY, None, g1, g2,
                                P["dd"][i].view())
+                hi_view = c[7 - i].view(coff=UP_FILTERS[6 - i])
             else:
-                L.call("p2p_norm_act_bwd", self.dtype, B, res, res, f, P["rd"][1].ptr(), NULL, NULL, NULL, L.ACT_LEAKY,
-                       LEAKY_ALPHA, NULL, C.byref(g1), C.byref(g2), C.byref(P["dd"][1].view()), NULL, NULL, _stream())
-            hi_view = c[6].view(coff=UP_FILTERS[5]) if i == 1 else (c[7 - i].view(coff=UP_FILTERS[6 - i]))
-            self._wgrad(P, "G", f"down{i}", B, res, cin, f, hi_view, P["dd"][i].view())
+                self._act_bwd(B, res, f, c[5].view(coff=UP_FILTERS[4]), g1, g2, P["dd"][1].view())
+                hi_view = P["src"].view()
+            self._wgrad(P, "G", f"down{i}", B, res, hi_view, P["dd"][i].view())
             if i > 1:
-                rk = self._conv(P, L.OP_P, "G", f"down{i}", B, res, cin, f, ga[i - 1].view(), P["dd"][i].view(), ga[i - 1])
-                g_from_down = self._gs(P, ga[i - 1], self._materialise(P, ga[i - 1], rk), 0)
+                rk = self._conv(P, L.OP_P, "G", f"down{i}", B, res, P["dd"][i].view(), ga[i - 1].view())
+                self._materialise(P, ga[i - 1], rk)
+                g_from_down = ga[i - 1].gsrc()
 
     def _materialise(self, P, buf, rk):
         """Split-K slabs are a single shared workspace: sum them into `buf` (activation dtype) right away so
@@ -573,7 +634,7 @@ class Pix2PixEngine:
         self.refresh_weight_copies()
 
     def _histogram_loss(self, P, B, Bg, lambda_hist, allreduce):
-        raise NotImplementedError("histogram loss kernels are wired in engine_hist")
+        raise NotImplementedError("histogram loss kernels are not wired yet")
 
     # ------------------------------------------------------------------ inference-style helpers
     def generate(self, source, masks=None):
@@ -585,7 +646,7 @@ class Pix2PixEngine:
         P = self.plan(B)
         S = self.S
         src_t = self._to_device(source, self.in_ch, B)
-        self._pack(P, src_t, P["c"][6].view(coff=UP_FILTERS[5]), self.in_ch)
+        self._pack_source(P, src_t)
         self.generator_forward(P, masks)
         fake_view = P["dcat"].view(coff=0, n0=B)
         # tanh through the loss kernel (its L1 output lands in a scratch slot and is ignored)

@@ -248,3 +248,57 @@ def test_bad_arguments_fail_loudly():
         L.call("p2p_igemm", L.OP_G, L.BF16, 1, 4, 4, 48, 64, C.byref(t), C.byref(t), None, 1, None, None)
     with pytest.raises(L.P2PError):
         L.call("p2p_conv_direct", 7, 2, L.F32, 1, 4, 4, 4, 4, C.byref(t), C.byref(t), None, None, None, None, None)
+
+
+def _pad_view_input(x, cpad, dtype):
+    """numpy (N,H,W,C) -> HaloBuf with C padded (zeros) to cpad channels."""
+    n, h, w, c = x.shape
+    xp = np.zeros((n, h, w, cpad), np.float32)
+    xp[..., :c] = x
+    return U.halo_from(xp, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lh,cg,cd,stride", [(2, 8, 4, 64, 2), (3, 8, 8, 64, 2), (2, 16, 36, 4, 1), (2, 8, 64, 1, 1),
+                                                (1, 4, 33, 256, 1), (2, 8, 1, 64, 2)])
+def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride):
+    """The edge layers (networks.py:46-48,57,75-78) through p2p_igemm_edge / p2p_wgemm_edge: padded channel
+    counts, stride 1 and 2, bias + LeakyReLU epilogue, masked columns."""
+    rng = np.random.default_rng(16)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, stride, dtype)
+    bias = rng.normal(size=cd).astype(np.float32)
+    g_ref, p_ref, w_ref = oracle_ops(hi, lo, w, stride)
+    hi_pad, lo_pad = E.pad8(cg), E.pad8(cd)
+    hi_b, lo_b = _pad_view_input(hi, hi_pad, dtype), _pad_view_input(lo, lo_pad, dtype)
+    wt = torch.zeros(16 * E.up32(cd) * hi_pad, dtype=U.tdt(dtype), device=U.DEV)
+    wn = torch.zeros(16 * E.up32(cg) * lo_pad, dtype=U.tdt(dtype), device=U.DEV)
+    L.call("p2p_weight_prep_pad", dtype, U.ptr(U.dev(w.reshape(-1))), cg, cd, U.ptr(wn), E.up32(cg), lo_pad,
+           U.ptr(wt), E.up32(cd), hi_pad, U.stream())
+    # op G with bias + LeakyReLU into a channel slice of a wider haloed buffer
+    out_g = E.HaloBuf(n, lh, lh, cd + 8, dtype, U.DEV)
+    L.call("p2p_igemm_edge", L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd, E.up32(cd), C.byref(hi_b.view()),
+           C.byref(out_g.view(coff=8)), U.ptr(wt), U.ptr(U.dev(bias)), L.ACT_LEAKY, 0.3, U.stream())
+    want = g_ref + bias
+    want = np.where(want > 0, want, 0.3 * want)
+    got = U.halo_to_np(out_g)
+    assert np.count_nonzero(got[..., :8]) == 0
+    assert U.rel_err(got[..., 8:], want) < OUT_TOL[dtype]
+    # op P restricted to the first ncols output channels
+    ncols = min(cg, 32)
+    out_p = E.DenseBuf(n, stride * lh, stride * lh, hi_pad, U.tdt(dtype), U.DEV)
+    out_p.t.zero_()
+    L.call("p2p_igemm_edge", L.OP_P, stride, dtype, n, lh, lh, lo_pad, ncols, E.up32(cg), C.byref(lo_b.view()),
+           C.byref(out_p.view()), U.ptr(wn), None, L.ACT_NONE, 0.0, U.stream())
+    gp = U.dense_to_np(out_p)
+    assert U.rel_err(gp[..., :ncols], p_ref[..., :ncols]) < OUT_TOL[dtype] * max(1.0, np.abs(p_ref).max() / (np.abs(p_ref[..., :ncols]).max() + 1e-30))
+    assert np.count_nonzero(gp[..., ncols:]) == 0
+    # op W with masked stores
+    for msplit in (1, 2):
+        dw = torch.full((16 * cg * cd,), float("nan"), dtype=torch.float32, device=U.DEV)
+        ws = torch.empty(max(L.lib().p2p_wgemm_workspace_bytes(n, lh, lh, cg, cd, msplit) // 4, 4), dtype=torch.float32, device=U.DEV)
+        L.call("p2p_wgemm_edge", dtype, stride, n, lh, lh, cg, cd, C.byref(hi_b.view()), C.byref(lo_b.view()), U.ptr(dw),
+               msplit, U.ptr(ws), U.stream())
+        assert U.rel_err(dw.cpu().numpy().reshape(4, 4, cg, cd), w_ref) < 2e-5, msplit
+    db = torch.empty(cd, dtype=torch.float32, device=U.DEV)
+    L.call("p2p_view_colsum", dtype, n, lh, lh, cd, C.byref(lo_b.view()), U.ptr(db), U.stream())
+    assert U.rel_err(db.cpu().numpy(), lo.astype(np.float64).sum(axis=(0, 1, 2))) < 2e-5
