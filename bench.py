@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-mfma", action="store_true")
+    ap.add_argument("--detail", default=None, help="write a per-call (entry point, shape) device-time table to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,6 +176,8 @@ def main():
             prof, records = kernel_profile(eng, run_step)
             result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype, MFMA_PEAK[args.dtype])
+            if args.detail:
+                FL.write_detail(records, args.detail, n_steps=3)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(model, S, lam_l1, lam_hist)
         print(json.dumps(result), flush=True)

@@ -138,6 +138,11 @@ int p2p_act_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* act_out
 /* out[c] = scale * sum_r part[r][c] (f32): batch reduction of dgamma/dbeta partials, loss partials. */
 int p2p_colsum(const float* part, int rows, int cols, float scale, float* out, void* stream);
 
+/* Batched form: task t sums the dense [rows][cols] block at part + table[t][0] over rows into out + table[t][3];
+ * table = device int32[ntasks][4] = {part_off, rows, cols, out_off}.  One launch reduces the dgamma/dbeta
+ * partials of every InstanceNorm layer of a backward pass. */
+int p2p_colsum_batched(const float* part, const int* table, int ntasks, int max_cols, float* out, void* stream);
+
 /* ---- losses (pix2pix_model.py:44-56) ------------------------------------------------------------ */
 
 /* logits: view [N2][H][W][1]; images [0,n_real) are D(real), the rest D(fake).

@@ -39,6 +39,7 @@ SIGNATURES = {
     "p2p_norm_act_fwd": [_i, _i, _i, _i, _i, _vp, _i, _i, _ll, _vp, _vp, _f, _i, _f, _vp, _TP, _vp, _vp, _vp],
     "p2p_norm_act_bwd": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _GP, _GP, _TP, _vp, _vp, _vp],
     "p2p_colsum": [_vp, _i, _i, _f, _vp, _vp],
+    "p2p_colsum_batched": [_vp, _vp, _i, _i, _vp, _vp],
     "p2p_bce_logits": [_i, _i, _i, _i, _i, _TP, _f, _TP, _TP, _vp, _vp],
     "p2p_tanh_l1_fwd": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp],
     "p2p_tanh_l1_bwd": [_i, _i, _i, _i, _i, _TP, _TP, _GP, _GP, _f, _TP, _vp],

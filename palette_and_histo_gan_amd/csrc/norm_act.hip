@@ -151,6 +151,246 @@ __global__ void norm_act_bwd_kernel(int H, int W, int C, int CB, const T* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Vectorised variants (C % (16/sizeof(T)) == 0, 16-byte aligned views): one workgroup = one image x one
+// group of <= 64 channels; every lane moves 16 bytes (8 bf16 / 4 f32 channels of one pixel) per access, so a
+// wave reads whole 128-byte pixel segments.  Pass 1 reduces per channel over the image (shifted sums: the
+// first pixel's value is subtracted before squaring, so E[x^2]-E[x]^2 does not cancel), pass 2 re-reads the
+// image (L2-resident: <= 512 KB per workgroup) and writes the result.
+template <typename T> struct VecOf;
+template <> struct VecOf<bf16_t> { static constexpr int N = 8; typedef bf16x8 type; };
+template <> struct VecOf<float> { static constexpr int N = 4; typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ void vload(const T* p, float* v) {
+    typename VecOf<T>::type r = *(const typename VecOf<T>::type*)p;
+#pragma unroll
+    for (int k = 0; k < VecOf<T>::N; ++k) v[k] = to_f32((T)r[k]);
+}
+template <typename T>
+__device__ __forceinline__ void vstore(T* p, const float* v) {
+    typename VecOf<T>::type r;
+#pragma unroll
+    for (int k = 0; k < VecOf<T>::N; ++k) r[k] = from_f32<T>(v[k]);
+    *(typename VecOf<T>::type*)p = r;
+}
+
+template <typename T>
+__device__ __forceinline__ void raw_vload(const void* raw, int raw_kind, int nslabs, long long slab, long long e, float* v) {
+    constexpr int VN = VecOf<T>::N;
+    if (raw_kind == 1) { vload<T>((const T*)raw + e, v); return; }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) v[k] = 0.f;
+    const float* p = (const float*)raw + e;
+    for (int sIdx = 0; sIdx < nslabs; ++sIdx) {
+#pragma unroll
+        for (int k = 0; k < VN; k += 4) {
+            f32x4 r = *(const f32x4*)(p + (long long)sIdx * slab + k);
+            v[k] += r[0]; v[k + 1] += r[1]; v[k + 2] += r[2]; v[k + 3] += r[3];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) v[k] = to_f32(from_f32<T>(v[k]));
+}
+
+template <typename T>
+__device__ __forceinline__ void gsrc_vload(const GSrc& g, long long pix, int c, float* v) {
+    constexpr int VN = VecOf<T>::N;
+    if (g.kind == 0) {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) v[k] = 0.f;
+        return;
+    }
+    long long e = pix * g.ld + g.coff + c;
+    if (g.kind == 1) { vload<T>((const T*)g.ptr + e, v); return; }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) v[k] = 0.f;
+    const float* p = (const float*)g.ptr + e;
+    for (int sIdx = 0; sIdx < g.nslabs; ++sIdx)
+#pragma unroll
+        for (int k = 0; k < VN; ++k) v[k] += p[(long long)sIdx * g.slab + k];
+}
+
+__device__ __forceinline__ void mask_vload8(const unsigned char* m, float* keep, int VN) {
+    if (VN == 8) {
+        unsigned long long r = *(const unsigned long long*)m;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) keep[k] = ((r >> (8 * k)) & 0xff) ? 2.f : 0.f;
+    } else {
+        unsigned r = *(const unsigned*)m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) keep[k] = ((r >> (8 * k)) & 0xff) ? 2.f : 0.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int CG, const void* __restrict__ raw,
+                                                        int raw_kind, int nslabs, long long slab,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int act, float alpha,
+                                                        const unsigned char* __restrict__ mask, TView out,
+                                                        T* __restrict__ raw_out, float* __restrict__ stats) {
+    constexpr int VN = VecOf<T>::N;
+    __shared__ float red[2][256 * 8 / 8 * 8];      // [2][PR][CG] with PR*CG/VN*VN <= 2048
+    const int n = blockIdx.x;
+    const int cg0 = blockIdx.y * CG;
+    const int VPP = CG / VN, PR = 256 / VPP;
+    const int vid = threadIdx.x % VPP, pr = threadIdx.x / VPP;
+    const int c = cg0 + vid * VN;
+    const int HW = H * W;
+    const long long base = (long long)n * HW * C + c;
+    float mu[VN], rs[VN], ga[VN], be[VN];
+    if (gamma) {
+        float sh[VN], s1[VN], s2[VN];
+        raw_vload<T>(raw, raw_kind, nslabs, slab, base, sh);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+        for (int p = pr; p < HW; p += PR) {
+            float x[VN];
+            raw_vload<T>(raw, raw_kind, nslabs, slab, base + (long long)p * C, x);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { float d = x[k] - sh[k]; s1[k] += d; s2[k] += d * d; }
+        }
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int i = 0; i < PR; ++i) { t1 += red[0][i * CG + vid * VN + k]; t2 += red[1][i * CG + vid * VN + k]; }
+            float m = t1 / (float)HW;
+            float var = fmaxf(t2 / (float)HW - m * m, 0.f);
+            mu[k] = sh[k] + m;
+            rs[k] = rsqrtf(var + eps);
+            ga[k] = gamma[c + k];
+            be[k] = beta[c + k];
+            if (pr == 0) {
+                stats[((long long)n * C + c + k) * 2 + 0] = mu[k];
+                stats[((long long)n * C + c + k) * 2 + 1] = rs[k];
+            }
+        }
+    }
+    for (int p = pr; p < HW; p += PR) {
+        long long e = base + (long long)p * C;
+        float x[VN], keep[VN];
+        raw_vload<T>(raw, raw_kind, nslabs, slab, e, x);
+        if (raw_out) vstore<T>(raw_out + e, x);
+        if (mask) mask_vload8(mask + e, keep, VN);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float y = gamma ? (x[k] - mu[k]) * rs[k] * ga[k] + be[k] : x[k];
+            if (mask) y *= keep[k];
+            if (act == P2P_ACT_LEAKY) y = y > 0.f ? y : alpha * y;
+            else if (act == P2P_ACT_RELU) y = y > 0.f ? y : 0.f;
+            x[k] = y;
+        }
+        int yy = p / W, xx = p - yy * W;
+        vstore<T>((T*)out.ptr + out.off(n, yy, xx) + c, x);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int CG, const T* __restrict__ raw,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int act, float alpha,
+                                                        const unsigned char* __restrict__ mask, GSrc g1, GSrc g2,
+                                                        TView draw, float* __restrict__ dgamma_part,
+                                                        float* __restrict__ dbeta_part) {
+    constexpr int VN = VecOf<T>::N;
+    __shared__ float red[2][2048];
+    const int n = blockIdx.x;
+    const int cg0 = blockIdx.y * CG;
+    const int VPP = CG / VN, PR = 256 / VPP;
+    const int vid = threadIdx.x % VPP, pr = threadIdx.x / VPP;
+    const int c = cg0 + vid * VN;
+    const int HW = H * W;
+    const long long pix0 = (long long)n * HW;
+    const long long base = pix0 * C + c;
+    float mu[VN], rs[VN], ga[VN], be[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        mu[k] = stats[((long long)n * C + c + k) * 2 + 0];
+        rs[k] = stats[((long long)n * C + c + k) * 2 + 1];
+        ga[k] = gamma[c + k];
+        be[k] = beta[c + k];
+    }
+    // d(yhat) and xhat of one pixel
+    auto dyhat = [&](int p, float* d, float* xh) {
+        long long e = base + (long long)p * C;
+        float x[VN], a1[VN], a2[VN], keep[VN];
+        vload<T>(raw + e, x);
+        gsrc_vload<T>(g1, pix0 + p, c, a1);
+        gsrc_vload<T>(g2, pix0 + p, c, a2);
+        if (mask) mask_vload8(mask + e, keep, VN);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            xh[k] = (x[k] - mu[k]) * rs[k];
+            float a = xh[k] * ga[k] + be[k];
+            float kp = mask ? keep[k] : 1.f;
+            a *= kp;
+            float slope = 1.f;
+            if (act == P2P_ACT_LEAKY) slope = a > 0.f ? 1.f : alpha;
+            else if (act == P2P_ACT_RELU) slope = a > 0.f ? 1.f : 0.f;
+            d[k] = (a1[k] + a2[k]) * slope * kp;
+        }
+    };
+    float s1[VN], s2[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    for (int p = pr; p < HW; p += PR) {
+        float d[VN], xh[VN];
+        dyhat(p, d, xh);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { s1[k] += d[k]; s2[k] += d[k] * xh[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
+    __syncthreads();
+    float m1[VN], m2[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int i = 0; i < PR; ++i) { t1 += red[0][i * CG + vid * VN + k]; t2 += red[1][i * CG + vid * VN + k]; }
+        if (pr == 0) {
+            dbeta_part[(long long)n * C + c + k] = t1;
+            dgamma_part[(long long)n * C + c + k] = t2;
+        }
+        m1[k] = t1 / (float)HW;
+        m2[k] = t2 / (float)HW;
+    }
+    for (int p = pr; p < HW; p += PR) {
+        float d[VN], xh[VN];
+        dyhat(p, d, xh);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) d[k] = ga[k] * rs[k] * (d[k] - m1[k] - xh[k] * m2[k]);
+        int yy = p / W, xx = p - yy * W;
+        vstore<T>((T*)draw.ptr + draw.off(n, yy, xx) + c, d);
+    }
+}
+
+// Batched column sums: task t reduces part[off_t .. off_t + rows*cols) (dense [rows][cols]) over rows into
+// out[out_off_t .. + cols).  table = int32[ntasks][4] = {part_off, rows, cols, out_off} on the device.
+// One launch replaces the per-layer dgamma/dbeta reductions of a whole backward pass.
+__global__ void colsum_batched_kernel(const float* __restrict__ part, const int* __restrict__ table,
+                                      float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int* t = table + 4 * blockIdx.y;
+    const int poff = t[0], rows = t[1], cols = t[2], ooff = t[3];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = rg; r < rows; r += 4) s += part[(long long)poff + (long long)r * cols + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols) out[ooff + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+extern "C" int p2p_colsum_batched(const float* part, const int* table, int ntasks, int max_cols, float* out, void* stream) {
+    P2P_REQUIRE(part && table && out && ntasks > 0 && max_cols > 0, "p2p_colsum_batched: bad args");
+    colsum_batched_kernel<<<dim3((max_cols + 63) / 64, ntasks), 256, 0, (hipStream_t)stream>>>(part, table, out);
+    return p2p_check_launch("p2p_colsum_batched");
+}
+
 // Backward of a bare activation whose OUTPUT is stored (LeakyReLU fused into the conv epilogue of down1 / D.down,
 // networks.py:19,46,58): sign(out) == sign(pre-activation), so d(pre) = (g1 + g2) * (out > 0 ? 1 : alpha).
 template <typename T>
@@ -168,9 +408,46 @@ __global__ void act_bwd_kernel(int N, int H, int W, int C, TView actv, GSrc g1, 
     }
 }
 
+template <typename T>
+__global__ void act_bwd_vec_kernel(int N, int H, int W, int C, TView actv, GSrc g1, GSrc g2, float alpha, TView draw) {
+    constexpr int VN = VecOf<T>::N;
+    const int cv = C / VN;
+    long long total = (long long)N * H * W * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * VN;
+        long long p = i / cv;
+        int x = (int)(p % W);
+        int y = (int)((p / W) % H);
+        int n = (int)(p / ((long long)W * H));
+        float a[VN], ga[VN], gb[VN];
+        vload<T>((const T*)actv.ptr + actv.off(n, y, x) + c, a);
+        gsrc_vload<T>(g1, p, c, ga);
+        gsrc_vload<T>(g2, p, c, gb);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { float g = ga[k] + gb[k]; a[k] = a[k] > 0.f ? g : alpha * g; }
+        vstore<T>((T*)draw.ptr + draw.off(n, y, x) + c, a);
+    }
+}
+
 extern "C" int p2p_act_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* act_out, const p2p_gsrc* g1,
                            const p2p_gsrc* g2, float alpha, const p2p_tensor* draw, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && act_out && act_out->ptr && g1 && draw && draw->ptr, "p2p_act_bwd: bad args");
+    {
+        const int esz = dtype == P2P_BF16 ? 2 : 4, vn = 16 / esz;
+        auto gs_ok = [&](const p2p_gsrc* g) {
+            if (!g || !g->ptr || g->kind == 0) return true;
+            return g->kind != 1 || (g->ld % vn == 0 && g->coff % vn == 0 && ((uintptr_t)g->ptr % 16) == 0);
+        };
+        if (C % 8 == 0 && act_out->ld % vn == 0 && draw->ld % vn == 0 && ((uintptr_t)act_out->ptr % 16) == 0 &&
+            ((uintptr_t)draw->ptr % 16) == 0 && gs_ok(g1) && gs_ok(g2)) {
+            long long tv = (long long)N * H * W * (C / vn);
+            long long bl = (tv + 255) / 256;
+            if (bl > 8192) bl = 8192;
+            P2P_DISPATCH_DTYPE(dtype, (act_bwd_vec_kernel<T><<<dim3((unsigned)bl), 256, 0, (hipStream_t)stream>>>(
+                                          N, H, W, C, make_view(act_out), make_gsrc(g1), make_gsrc(g2), alpha, make_view(draw))));
+            return p2p_check_launch("p2p_act_bwd");
+        }
+    }
     long long total = (long long)N * H * W * C;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -198,6 +475,21 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
     P2P_REQUIRE(raw_kind == 1 || (raw_kind == 2 && nslabs >= 1), "p2p_norm_act_fwd: bad raw_kind/nslabs");
     P2P_REQUIRE((gamma == nullptr) == (beta == nullptr), "p2p_norm_act_fwd: gamma/beta must both be set or null");
     P2P_REQUIRE(!gamma || stats, "p2p_norm_act_fwd: stats required with normalisation");
+    const int esz = dtype == P2P_BF16 ? 2 : 4, vn = 16 / esz;
+    const bool vec = C % vn == 0 && out->ld % vn == 0 && ((uintptr_t)out->ptr % 16) == 0 && ((uintptr_t)raw % 16) == 0 &&
+                     (!raw_out || ((uintptr_t)raw_out % 16) == 0) && (raw_kind == 1 || slab_stride % 4 == 0) && C % 8 == 0;
+    if (vec) {
+        int CG = C > 64 ? 64 : C;
+        while (C % CG) CG -= vn;
+        int vpp = CG / vn;
+        if (256 % vpp == 0) {
+            dim3 grid(N, C / CG);
+            P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T><<<grid, 256, 0, (hipStream_t)stream>>>(
+                                          H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
+                                          make_view(out), (T*)raw_out, stats)));
+            return p2p_check_launch("p2p_norm_act_fwd");
+        }
+    }
     int CB = pick_cb(C);
     dim3 grid(N, (C + CB - 1) / CB);
     size_t shm = sizeof(float) * 256;
@@ -214,6 +506,26 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_norm_act_bwd: bad shape");
     P2P_REQUIRE(raw && draw && draw->ptr && g1, "p2p_norm_act_bwd: null pointer");
     P2P_REQUIRE(!gamma || (stats && beta && dgamma_part && dbeta_part), "p2p_norm_act_bwd: norm needs stats/beta/partials");
+    const int esz = dtype == P2P_BF16 ? 2 : 4, vn = 16 / esz;
+    auto gs_ok = [&](const p2p_gsrc* g) {
+        if (!g || !g->ptr || g->kind == 0) return true;
+        if (g->kind == 1) return g->ld % vn == 0 && g->coff % vn == 0 && ((uintptr_t)g->ptr % 16) == 0;
+        return true;    // f32 slabs are read element-wise
+    };
+    const bool vec = gamma && C % 8 == 0 && draw->ld % vn == 0 && ((uintptr_t)draw->ptr % 16) == 0 &&
+                     ((uintptr_t)raw % 16) == 0 && gs_ok(g1) && gs_ok(g2);
+    if (vec) {
+        int CG = C > 64 ? 64 : C;
+        while (C % CG) CG -= vn;
+        int vpp = CG / vn;
+        if (256 % vpp == 0) {
+            dim3 grid(N, C / CG);
+            P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T><<<grid, 256, 0, (hipStream_t)stream>>>(
+                                          H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
+                                          make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)));
+            return p2p_check_launch("p2p_norm_act_bwd");
+        }
+    }
     int CB = pick_cb(C);
     dim3 grid(N, (C + CB - 1) / CB);
     size_t shm = sizeof(float) * 512;

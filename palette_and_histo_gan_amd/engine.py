@@ -296,7 +296,18 @@ class Pix2PixEngine:
         # gradient sources: d(concat_k) for k=1..6, d(a_k) from the down path
         P["gc"] = [None] + [DenseBuf(B, P["c"][k].h, P["c"][k].w, P["c"][k].c, tdt, dev) for k in range(1, 7)]
         P["ga"] = {i: DenseBuf(B, S // 2 ** i, S // 2 ** i, DOWN_FILTERS[i - 1], tdt, dev) for i in range(1, 7)}
-        P["part"] = torch.empty((2, B, 1024), dtype=torch.float32, device=dev)     # dgamma/dbeta partials
+        # dgamma/dbeta per-image partials of every InstanceNorm layer + the task table of the one batched
+        # reduction that ends the backward pass: rows = {part_off, rows, cols, out_off}
+        P["part_off"], tasks, off = {}, [], 0
+        for name in [k[:-6] for k in self.G.shapes if k.endswith(".gamma")]:
+            cch = self.G.shapes[name + ".gamma"][0]
+            P["part_off"][name] = (off, off + B * cch)              # (dbeta partials, dgamma partials)
+            tasks.append([off, B, cch, self.G.offsets[name + ".beta"]])
+            tasks.append([off + B * cch, B, cch, self.G.offsets[name + ".gamma"]])
+            off += 2 * B * cch
+        P["part"] = torch.empty(off, dtype=torch.float32, device=dev)
+        P["part_tasks"] = torch.tensor(tasks, dtype=torch.int32, device=dev)
+        P["part_maxc"] = max(t[2] for t in tasks)
         # generator head
         P["z"] = DenseBuf(B, S, S, self.out_ch, tdt, dev)
         P["dz"] = HaloBuf(B, S, S, self.dz_ch, dt, dev)
@@ -332,12 +343,19 @@ class Pix2PixEngine:
         return sk
 
     def _msplit(self, B, lh, cg, cd):
+        """Pixel-range split of the weight-gradient GEMM.  Small output tiles (edge layers: 1-2 waves per
+        workgroup, 24-48 KB of LDS) are latency-bound streams over up to 1M pixels: give the chip >= 4096 waves.
+        The 128-wide tiles (4 waves, 64 KB of LDS, 2 workgroups per CU) want >= 512 workgroups."""
         bg = 128 if cg > 64 else (64 if cg > 32 else 32)
         bd = 128 if cd > 64 else (64 if cd > 32 else 32)
+        nw = (bg // 32) * (bd // 32)
+        nw = 4 if nw >= 4 else nw
         tiles = 16 * ((cg + bg - 1) // bg) * ((cd + bd - 1) // bd)
+        want = 512 if nw == 4 else 4096 // nw
+        min_chunk = 256 if nw == 4 else 1024
         m = B * lh * lh
         ms = 1
-        while tiles * ms < 512 and m // (ms * 2) >= 256:
+        while tiles * ms < want and m // (ms * 2) >= min_chunk:
             ms *= 2
         return ms
 
@@ -436,14 +454,10 @@ class Pix2PixEngine:
         return L.GSrc(P["slabs"].data_ptr(), 2, rk[1], buf.n * buf.h * buf.w * buf.c, buf.c, coff)
 
     def _norm_bwd(self, P, name, N, res, c, raw_buf, stats, act, mask, g1, g2, draw_view):
-        part = P["part"]
+        ob, og = P["part_off"][name]
         L.call("p2p_norm_act_bwd", self.dtype, N, res, res, c, raw_buf.ptr(), _p(stats), self.G.p(name + ".gamma"),
                self.G.p(name + ".beta"), act, LEAKY_ALPHA, _p(mask) if mask is not None else NULL, C.byref(g1),
-               C.byref(g2) if g2 is not None else None, C.byref(draw_view), _p(part[1]), _p(part[0]), _stream())
-        # batch reduction of the per-image partials (dense [N][c] at the start of each scratch plane) into the
-        # flat gradient buffer: dgamma/dbeta sum over batch AND space
-        L.call("p2p_colsum", _p(part[1]), N, c, 1.0, self.G.g(name + ".gamma"), _stream())
-        L.call("p2p_colsum", _p(part[0]), N, c, 1.0, self.G.g(name + ".beta"), _stream())
+               C.byref(g2) if g2 is not None else None, C.byref(draw_view), _p(P["part"], og), _p(P["part"], ob), _stream())
 
     def _act_bwd(self, N, res, c, act_view, g1, g2, draw_view):
         L.call("p2p_act_bwd", self.dtype, N, res, res, c, C.byref(act_view), C.byref(g1),
@@ -601,6 +615,10 @@ class Pix2PixEngine:
                 rk = self._conv(P, L.OP_P, "G", f"down{i}", B, res, P["dd"][i].view(), ga[i - 1].view())
                 self._materialise(P, ga[i - 1], rk)
                 g_from_down = ga[i - 1].gsrc()
+        # dgamma/dbeta sum over batch AND space: one batched reduction of every layer's
+        # per-image partials into the flat gradient buffer
+        L.call("p2p_colsum_batched", _p(P["part"]), _p(P["part_tasks"]), int(P["part_tasks"].shape[0]), P["part_maxc"],
+               _p(self.G.grads), _stream())
 
     def _materialise(self, P, buf, rk):
         """Split-K slabs are a single shared workspace: sum them into `buf` (activation dtype) right away so

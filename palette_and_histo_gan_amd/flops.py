@@ -70,3 +70,21 @@ def roofline_for_dominant(prof, records, B, S, dtype, peak_tflops):
     return {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tflops, "unit": "TFLOP/s",
             "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": n,
             "avg_launch_ms": round(ms / n, 5), "flops_per_launch_avg": fl / n}
+
+
+def write_detail(records, path, n_steps):
+    """Per-call table: entry point, leading integer arguments (shape), ms per launch, algorithmic TFLOP/s."""
+    agg = {}
+    for name, args, a, b in records:
+        ints = tuple(x for x in args if isinstance(x, int))
+        key = (name, ints)
+        d = agg.setdefault(key, [0.0, 0])
+        d[0] += a.elapsed_time(b)
+        d[1] += 1
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+    with open(path, "w") as f:
+        f.write("ms_per_step  launches  ms_each  TFLOP/s  entry  int-args\n")
+        for (name, ints), (ms, n) in rows:
+            fl = _call_flops(name, ints)
+            tf = (fl * n / (ms * 1e-3) / 1e12) if fl else 0.0
+            f.write(f"{ms / n_steps:10.4f} {n / n_steps:8.1f} {ms / n:9.4f} {tf:8.1f}  {name} {ints}\n")
