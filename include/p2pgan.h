@@ -161,6 +161,42 @@ int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fak
                     const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale,
                     const p2p_tensor* dz, void* stream);
 
+/* ---- RGB-uv histogram + Hellinger loss (histogram.py:4-89, pix2pix_model.py:242-250) ------------------------- */
+
+/* Raw (unnormalised) histogram of the RGB channels of `img` ([-1,1] images): hist[N][3][64][64] f32 with
+ * hist[n][c][i][j] = sum_p Iy[p] k(u_p - d_i) k(v_p - d_j) for component c (the reference's (B,64,64,3) tensor
+ * transposed and before its division by the per-image total, histogram.py:75-79). */
+int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tensor* img, float* hist, void* stream);
+
+/* out[N][64][64][3] = raw[N][3][64][64] transposed and divided by the per-image total (histogram.py:75-79). */
+int p2p_hist_normalize(const float* raw, int N, float* out, void* stream);
+
+/* Per-image totals of both raw histograms and the LOCAL Hellinger sum of squares
+ * sq_sum[0] = sum_{n,c,i,j} (sqrt(pred/tot_pred) - sqrt(true/tot_true))^2 (histogram.py:88-89).  Under data
+ * parallelism sq_sum is all-reduced (SUM) before the two calls below. */
+int p2p_hellinger_fwd(const float* hist_true, const float* hist_pred, int N, float* tot_true, float* tot_pred,
+                      float* sq_sum, void* stream);
+/* loss_out[0] = sqrt(sq_sum) / (sqrt(2) * B_global). */
+int p2p_hellinger_finish(const float* sq_sum, float inv_global_batch, float* loss_out, void* stream);
+/* d(coef' * hellinger)/d(fake image) with coef = lambda_hist / (2*sqrt(2)*B_global): writes three f32 slabs
+ * dimg[3][N*H*W][4] (one per colour component, alpha gradient 0) that the consumer sums; gh_ws is a
+ * [N][3][64][64] f32 workspace. */
+int p2p_rgbuv_hist_hellinger_bwd(int dtype, int N, int H, int W, const p2p_tensor* fake, const float* hist_true,
+                                 const float* hist_pred, const float* tot_true, const float* tot_pred,
+                                 const float* sq_sum, float coef, float* gh_ws, float* dimg, void* stream);
+
+/* ---- palette-index head (pix2pix_model.py:261-325) ------------------------------------------------------------ */
+
+/* z: logits view [N][H][W][C]; target: view holding the real palette index of every pixel (as a value of `dtype`).
+ * Writes argmax(softmax(z)) (ties -> lowest index) into fake_idx as a value of `dtype`, optionally
+ * dz = grad_scale * (softmax(z) - onehot(target)) and the f32 probabilities; loss_out[0] = inv_count * sum CCE,
+ * loss_out[1] = inv_count / C * sum |onehot - p|. */
+int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* target,
+                           const p2p_tensor* fake_idx, float grad_scale, float inv_count, const p2p_tensor* dz,
+                           float* probs_out, float* loss_out, void* stream);
+/* tf.argmax(probs, axis=-1, output_type=int32) on dense f32 probabilities [M][C]; ties -> lowest index. */
+int p2p_argmax_lastdim(const float* probs, long long M, int C, int* out, void* stream);
+
 /* ---- optimizer / parameter plumbing (pix2pix_model.py:28-29,81-83) ------------------------------- */
 
 /* Keras Adam over a flat f32 buffer; t = iteration AFTER increment; grads are multiplied by gscale first. */

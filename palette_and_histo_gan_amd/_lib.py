@@ -48,6 +48,13 @@ SIGNATURES = {
     "p2p_pack_input": [_i, _i, _i, _i, _i, _vp, _i, _TP, _vp],
     "p2p_unpack": [_i, _i, _i, _i, _i, _TP, _vp, _vp],
     "p2p_dropout_mask": [_vp, _ll, _ll, _ll, _vp],
+    "p2p_rgbuv_hist_fwd": [_i, _i, _i, _i, _TP, _vp, _vp],
+    "p2p_hist_normalize": [_vp, _i, _vp, _vp],
+    "p2p_hellinger_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "p2p_hellinger_finish": [_vp, _f, _vp, _vp],
+    "p2p_rgbuv_hist_hellinger_bwd": [_i, _i, _i, _i, _TP, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
+    "p2p_softmax_cce_argmax": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _f, _TP, _vp, _vp, _vp],
+    "p2p_argmax_lastdim": [_vp, _ll, _i, _vp, _vp],
 }
 SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
            "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong)}

@@ -118,7 +118,9 @@ extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_
                                void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_tanh_l1_bwd: bad shape");
     P2P_REQUIRE(fake && fake->ptr && real && real->ptr && dz && dz->ptr, "p2p_tanh_l1_bwd: null pointer");
-    P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T><<<dim3(grid_for((long long)N * H * W * C)), 256, 0, (hipStream_t)stream>>>(
+    long long blocks = ((long long)N * H * W * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
                                   N, H, W, C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
                                   l1_scale, make_view(dz))));
     return p2p_check_launch("p2p_tanh_l1_bwd");

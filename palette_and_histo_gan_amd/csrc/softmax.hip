@@ -1,0 +1,137 @@
+// Palette-index head of Pix2PixIndexedModel (pix2pix_model.py:261-325): softmax over the 256 palette slots
+// (networks.py:75-78 with last_activation="softmax"), tf.argmax(..., output_type=int32) (:286,292; ties -> lowest
+// index), CategoricalCrossentropy against one_hot(real) (:265,274,300-301) and its gradient.  The one-hot tensor and
+// the (B,S,S,256) probabilities are never materialised unless asked for: one wave owns one pixel, 4 logits per lane.
+#include "p2p_common.hpp"
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// loss_out[0] += inv_count * sum_pixels -log p[target]          (segmentation loss, mean over pixels)
+// loss_out[1] += inv_count/C * sum_pixels sum_c |onehot - p|    (the reported, zero-weighted L1 term, :263,273-278)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, int W, int C, TView z, TView target,
+                                                                TView fake_idx, float grad_scale, float inv_count,
+                                                                TView dz, float* __restrict__ probs_out,
+                                                                float* __restrict__ loss_out) {
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long M = (long long)N * H * W;
+    const int per = (C + 63) / 64;          // logits per lane (4 for C = 256)
+    float seg = 0.f, l1 = 0.f;
+    for (long long m = wave_id; m < M; m += nwaves) {
+        int x = (int)(m % W);
+        int y = (int)((m / W) % H);
+        int n = (int)(m / ((long long)W * H));
+        const T* zp = (const T*)z.ptr + z.off(n, y, x);
+        float v[8];
+        float mx = -INFINITY;
+        for (int k = 0; k < per; ++k) {
+            int c = lane * per + k;
+            v[k] = c < C ? to_f32(zp[c]) : -INFINITY;
+            mx = fmaxf(mx, v[k]);
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int k = 0; k < per; ++k) { v[k] = expf(v[k] - mx); s += v[k]; }
+        s = wave_sum(s);
+        // probabilities exactly as tf.nn.softmax forms them: exp(z - max) / sum
+        float best = -1.f;
+        int besti = 0;
+        for (int k = 0; k < per; ++k) {
+            v[k] = v[k] / s;
+            int c = lane * per + k;
+            if (c < C && v[k] > best) { best = v[k]; besti = c; }     // strict '>' keeps the lowest index within the lane
+        }
+        // argmax across lanes, ties -> lowest index
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(besti, o, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        int t = (int)to_f32(((const T*)target.ptr)[target.off(n, y, x)]);
+        float pt = 0.f;
+        for (int k = 0; k < per; ++k)
+            if (lane * per + k == t) pt = v[k];
+        pt = wave_sum(pt);          // exactly one lane holds it
+        if (lane == 0) {
+            ((T*)fake_idx.ptr)[fake_idx.off(n, y, x)] = from_f32<T>((float)besti);
+            seg += -(logf(pt));
+            l1 += 2.f * (1.f - pt);          // sum_c |onehot_c - p_c| = (1 - p_t) + sum_{c != t} p_c
+        }
+        if (dz.ptr) {
+            T* dp = (T*)dz.ptr + dz.off(n, y, x);
+            for (int k = 0; k < per; ++k) {
+                int c = lane * per + k;
+                if (c < C) dp[c] = from_f32<T>((v[k] - (c == t ? 1.f : 0.f)) * grad_scale);
+            }
+        }
+        if (probs_out)
+            for (int k = 0; k < per; ++k) {
+                int c = lane * per + k;
+                if (c < C) probs_out[m * C + c] = v[k];
+            }
+    }
+    seg = block_sum(seg, red);
+    l1 = block_sum(l1, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_out + 0, seg * inv_count);
+        atomicAdd(loss_out + 1, l1 * inv_count / (float)C);
+    }
+}
+
+// argmax over the last dimension of given probabilities (pix2pix_model.py:286): int32, ties -> lowest index
+__global__ void argmax_lastdim_kernel(const float* __restrict__ p, long long M, int C, int* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long m = wave_id; m < M; m += nwaves) {
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            float v = p[m * C + c];
+            if (v > best) { best = v; besti = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(besti, o, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) out[m] = besti;
+    }
+}
+
+extern "C" int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* target,
+                                      const p2p_tensor* fake_idx, float grad_scale, float inv_count, const p2p_tensor* dz,
+                                      float* probs_out, float* loss_out, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C <= 512, "p2p_softmax_cce_argmax: bad shape (C <= 512)");
+    P2P_REQUIRE(z && z->ptr && target && target->ptr && fake_idx && fake_idx->ptr && loss_out, "p2p_softmax_cce_argmax: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(loss_out, 0, 2 * sizeof(float), st);
+    if (e != hipSuccess) { p2p_set_error("p2p_softmax_cce_argmax memset: %s", hipGetErrorString(e)); return (int)e; }
+    TView d;
+    if (dz && dz->ptr) d = make_view(dz);
+    else { d.ptr = nullptr; d.img = 0; d.row = 0; d.ld = 0; }
+    long long M = (long long)N * H * W;
+    long long blocks = (M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    P2P_DISPATCH_DTYPE(dtype, (softmax_cce_argmax_kernel<T><<<dim3((unsigned)blocks), 256, 0, st>>>(
+                                  N, H, W, C, make_view(z), make_view(target), make_view(fake_idx), grad_scale, inv_count, d,
+                                  probs_out, loss_out)));
+    return p2p_check_launch("p2p_softmax_cce_argmax");
+}
+
+extern "C" int p2p_argmax_lastdim(const float* probs, long long M, int C, int* out, void* stream) {
+    P2P_REQUIRE(probs && out && M > 0 && C > 0, "p2p_argmax_lastdim: bad args");
+    long long blocks = (M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    argmax_lastdim_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(probs, M, C, out);
+    return p2p_check_launch("p2p_argmax_lastdim");
+}

@@ -540,7 +540,7 @@ class Pix2PixEngine:
 
     # ------------------------------------------------------------------ train step (RGBA models)
     def train_step_rgba(self, source, real, lambda_l1, lambda_hist=None, masks=None, global_batch=None,
-                        apply_update=True, allreduce=None):
+                        apply_update=True, allreduce=None, hist_allreduce=None):
         """Pix2PixModel.train_step / Pix2PixHistogramModel (pix2pix_model.py:62-89,242-250).
         Returns a device tensor [g_total, g_adv, g_l1, g_hist, d_total, d_real, d_fake] (f32)."""
         B = int(source.shape[0])
@@ -564,7 +564,8 @@ class Pix2PixEngine:
                C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.losses, 0), _stream())
         g_extra = None
         if lambda_hist is not None:
-            g_extra = self._histogram_loss(P, B, Bg, lambda_hist, allreduce)
+            g_extra = self._histogram_loss(P, B, Bg, lambda_hist, hist_allreduce)
+        P["skip_g_through_d"] = False
         self.discriminator_backward(P, B)
         L.call("p2p_tanh_l1_bwd", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), C.byref(real_view),
                C.byref(P["g_dcat"].gsrc()), C.byref(g_extra) if g_extra is not None else None,
@@ -651,8 +652,106 @@ class Pix2PixEngine:
                    store.t, self.lr, self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
         self.refresh_weight_copies()
 
-    def _histogram_loss(self, P, B, Bg, lambda_hist, allreduce):
-        raise NotImplementedError("histogram loss kernels are not wired yet")
+    def _histogram_loss(self, P, B, Bg, lambda_hist, hist_allreduce):
+        """Pix2PixHistogramModel.generator_loss (pix2pix_model.py:242-250): Hellinger(rgbuv_hist(real), rgbuv_hist(fake)).
+        Returns the gradient source lambda_hist * d(hist_loss)/d(fake) (three f32 slabs, one per colour component).
+        The loss is sqrt(sum over the GLOBAL batch)/B_global, so under data parallelism the local sum of squares is
+        all-reduced between the forward and the backward kernels."""
+        S = self.S
+        if "h_real" not in P:
+            dev = self.device
+            P["h_real"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
+            P["h_fake"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
+            P["h_gh"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
+            P["h_tot"] = torch.empty((2, B), dtype=torch.float32, device=dev)
+            P["h_sq"] = torch.zeros(4, dtype=torch.float32, device=dev)
+            P["h_dimg"] = torch.empty(3 * B * S * S * 4, dtype=torch.float32, device=dev)
+        real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
+        L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(real_view), _p(P["h_real"]), _stream())
+        L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(fake_view), _p(P["h_fake"]), _stream())
+        L.call("p2p_hellinger_fwd", _p(P["h_real"]), _p(P["h_fake"]), B, _p(P["h_tot"][0]), _p(P["h_tot"][1]),
+               _p(P["h_sq"]), _stream())
+        if hist_allreduce is not None:
+            hist_allreduce(P["h_sq"][:1])
+        L.call("p2p_hellinger_finish", _p(P["h_sq"]), 1.0 / Bg, _p(self.losses, 4), _stream())
+        coef = float(lambda_hist) / (2.0 * math.sqrt(2.0) * Bg)
+        L.call("p2p_rgbuv_hist_hellinger_bwd", self.dtype, B, S, S, C.byref(fake_view), _p(P["h_real"]), _p(P["h_fake"]),
+               _p(P["h_tot"][0]), _p(P["h_tot"][1]), _p(P["h_sq"]), coef, _p(P["h_gh"]), _p(P["h_dimg"]), _stream())
+        return L.GSrc(P["h_dimg"].data_ptr(), 2, 3, B * S * S * 4, 4, 0)
+
+    def rgbuv_histogram(self, image):
+        """histogram.calculate_rgbuv_histogram (histogram.py:35-81) of a dense f32 (B,S,S,4) batch in [-1,1]:
+        returns the normalised (B,64,64,3) f32 device tensor in the reference's layout."""
+        B = int(image.shape[0])
+        S = self.S
+        img_t = self._to_device(image, 4, B)
+        buf = HaloBuf(B, S, S, 8, self.dtype, self.device)
+        L.call("p2p_pack_input", self.dtype, B, S, S, 4, _p(img_t), 0, C.byref(buf.view()), _stream())
+        raw = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=self.device)
+        L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(buf.view()), _p(raw), _stream())
+        out = torch.empty((B, 64, 64, 3), dtype=torch.float32, device=self.device)
+        L.call("p2p_hist_normalize", _p(raw), B, _p(out), _stream())
+        return out
+
+    # ------------------------------------------------------------------ train step (indexed model)
+    def train_step_indexed(self, source_idx, real_idx, lambda_segmentation, masks=None, global_batch=None,
+                           apply_update=True, allreduce=None):
+        """Pix2PixIndexedModel.train_step (pix2pix_model.py:295-325).  source/real: int (B,S,S,1) palette indices.
+        The discriminator sees un-normalised index images and the argmax blocks every gradient from D to G, so the
+        generator learns from lambda_seg * CCE only (lambda_l1 is hard-wired to 0, :263).
+        Returns [g_total, g_adv, g_l1, g_seg, d_total, d_real, d_fake]."""
+        assert self.head == "softmax" and self.in_ch == 1
+        B = int(source_idx.shape[0])
+        P = self.plan(B)
+        S = self.S
+        Bg = global_batch or B
+        src_t = self._to_device(source_idx, 1, B, is_int=True)
+        real_t = self._to_device(real_idx, 1, B, is_int=True)
+        self._pack_source(P, src_t)
+        self._pack(P, src_t, P["dcat"].view(coff=1), 1)
+        self._pack(P, src_t, P["dcat"].view(coff=1, n0=B), 1)
+        self._pack(P, real_t, P["dcat"].view(coff=0), 1)
+        self.generator_forward(P, masks)
+        real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
+        inv_pix = 1.0 / (Bg * S * S)
+        L.call("p2p_softmax_cce_argmax", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
+               C.byref(fake_view), float(lambda_segmentation) * inv_pix, inv_pix, C.byref(P["dz"].view()), NULL,
+               _p(self.losses, 5), _stream())
+        self.discriminator_forward(P, 2 * B)
+        h2 = S // 2
+        L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), 1.0 / (Bg * h2 * h2),
+               C.byref(P["dld"].view()), None, _p(self.losses, 0), _stream())
+        P["skip_g_through_d"] = True
+        self.discriminator_backward(P, B)
+        self.generator_backward(P)
+        if allreduce is not None:
+            allreduce(self.G.grads, self.D.grads, self.losses)
+        if apply_update:
+            self.apply_adam()
+        l = self.losses
+        g_adv, seg, l1 = l[2], l[5], l[6]
+        g_total = g_adv + 0.0 * l1 + float(lambda_segmentation) * seg
+        self.step_count += 1
+        return torch.stack([g_total, g_adv, l1, seg, l[0] + l[1], l[0], l[1]])
+
+    def generate_indexed(self, source_idx, masks=None, with_probs=False):
+        """Pix2PixIndexedModel.generate / generate_with_probs (pix2pix_model.py:283-293): int32 (B,S,S,1) argmax indices
+        (and the f32 (B,S,S,256) probabilities)."""
+        assert self.head == "softmax"
+        B = int(source_idx.shape[0])
+        P = self.plan(B)
+        S = self.S
+        src_t = self._to_device(source_idx, 1, B, is_int=True)
+        self._pack_source(P, src_t)
+        self.generator_forward(P, masks)
+        fake_view = P["dcat"].view(coff=0, n0=B)
+        probs = torch.empty((B, S, S, self.out_ch), dtype=torch.float32, device=self.device)
+        L.call("p2p_softmax_cce_argmax", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(fake_view),
+               C.byref(fake_view), 0.0, 0.0, None, _p(probs), _p(self.losses, 14), _stream())
+        idx = torch.empty((B * S * S,), dtype=torch.int32, device=self.device)
+        L.call("p2p_argmax_lastdim", _p(probs), B * S * S, self.out_ch, _p(idx), _stream())
+        idx = idx.view(B, S, S, 1)
+        return (idx, probs) if with_probs else idx
 
     # ------------------------------------------------------------------ inference-style helpers
     def generate(self, source, masks=None):

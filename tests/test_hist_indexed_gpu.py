@@ -1,0 +1,180 @@
+"""-m gpu: the histogram loss kernels (histogram.py:4-89), the palette-index head (pix2pix_model.py:261-325) and the
+two model variants' full train steps against the CPU oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_restatement as npr
+from oracle import reference_graph as rg
+from palette_and_histo_gan_amd import _lib as L
+from palette_and_histo_gan_amd import engine as E
+from tests import gpu_util as U
+from tests.test_train_step_gpu import grad_report, setup_case, to_np
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def test_rgbuv_histogram_forward_matches_oracle():
+    rng = np.random.default_rng(31)
+    src, tgt = rg.synthetic_rgba_batch(rng, 3, 64, palette_size=24)
+    fake = np.clip(src + rng.normal(scale=0.1, size=src.shape), -1, 1).astype(np.float32)
+    eng = E.Pix2PixEngine(4, 4, "tanh", 64, L.F32)
+    for img in (tgt, fake):
+        got = eng.rgbuv_histogram(img).cpu().numpy()
+        ref = rg.rgbuv_histogram(torch.tensor(img, dtype=F64)).numpy()
+        assert got.shape == (3, 64, 64, 3)
+        np.testing.assert_allclose(got.sum(axis=(1, 2, 3)), 1.0, rtol=1e-5)
+        assert U.rel_err(got, ref) < 2e-5
+    # all-transparent image: three identical planes, the four centre bins are the equal maxima
+    h = eng.rgbuv_histogram(np.full((1, 64, 64, 4), -1.0, np.float32)).cpu().numpy()[0]
+    assert np.allclose(h[..., 0], h[..., 1]) and np.allclose(h[..., 0], h[..., 2])
+    assert {tuple(ix) for ix in np.argwhere(h[..., 0] >= h[..., 0].max() * (1 - 1e-6))} == {(31, 31), (31, 32), (32, 31), (32, 32)}
+
+
+def test_histogram_tail_batches_small_image():
+    """HW not a multiple of the kernels' pixel batches (8x8 = 64 < 128) exercises the zero-weight tail."""
+    rng = np.random.default_rng(32)
+    src, _ = rg.synthetic_rgba_batch(rng, 2, 64, palette_size=8)
+    img = src[:, :8, :8, :].copy()
+    hb = U.halo_from(np.concatenate([img, np.zeros_like(img)], -1), L.F32)
+    raw = torch.empty(2 * 3 * 64 * 64, dtype=torch.float32, device=U.DEV)
+    L.call("p2p_rgbuv_hist_fwd", L.F32, 2, 8, 8, C.byref(hb.view()), U.ptr(raw), U.stream())
+    out = torch.empty((2, 64, 64, 3), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_hist_normalize", U.ptr(raw), 2, U.ptr(out), U.stream())
+    ref = npr.rgbuv_histogram(img.astype(np.float64))
+    assert U.rel_err(out.cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("size", [8, 64])
+def test_hellinger_loss_and_gradient_match_closed_form(size):
+    rng = np.random.default_rng(33)
+    B = 2
+    src, tgt = rg.synthetic_rgba_batch(rng, B, 64, palette_size=12)
+    src, tgt = src[:, :size, :size], tgt[:, :size, :size]
+    fake = np.clip(src + rng.normal(scale=0.05, size=src.shape), -1, 1).astype(np.float32)
+    ft = torch.tensor(fake, dtype=F64, requires_grad=True)
+    real_h = rg.rgbuv_histogram(torch.tensor(tgt, dtype=F64))
+    loss = rg.hellinger_loss(real_h, rg.rgbuv_histogram(ft))
+    loss.backward()
+    pad = lambda a: U.halo_from(np.concatenate([a, np.zeros_like(a)], -1), L.F32)
+    rb, fb = pad(tgt), pad(fake)
+    n = B * 3 * 64 * 64
+    h_r, h_f, gh = (torch.empty(n, dtype=torch.float32, device=U.DEV) for _ in range(3))
+    tot = torch.empty((2, B), dtype=torch.float32, device=U.DEV)
+    sq = torch.zeros(4, dtype=torch.float32, device=U.DEV)
+    out_loss = torch.zeros(1, dtype=torch.float32, device=U.DEV)
+    dimg = torch.empty(3 * B * size * size * 4, dtype=torch.float32, device=U.DEV)
+    L.call("p2p_rgbuv_hist_fwd", L.F32, B, size, size, C.byref(rb.view()), U.ptr(h_r), U.stream())
+    L.call("p2p_rgbuv_hist_fwd", L.F32, B, size, size, C.byref(fb.view()), U.ptr(h_f), U.stream())
+    L.call("p2p_hellinger_fwd", U.ptr(h_r), U.ptr(h_f), B, U.ptr(tot[0]), U.ptr(tot[1]), U.ptr(sq), U.stream())
+    L.call("p2p_hellinger_finish", U.ptr(sq), 1.0 / B, U.ptr(out_loss), U.stream())
+    assert abs(float(out_loss[0]) - float(loss)) < 1e-4 * float(loss)
+    L.call("p2p_rgbuv_hist_hellinger_bwd", L.F32, B, size, size, C.byref(fb.view()), U.ptr(h_r), U.ptr(h_f), U.ptr(tot[0]),
+           U.ptr(tot[1]), U.ptr(sq), 1.0 / (2.0 * math.sqrt(2.0) * B), U.ptr(gh), U.ptr(dimg), U.stream())
+    got = dimg.view(3, B, size, size, 4).sum(0).cpu().numpy()
+    ref = ft.grad.numpy()
+    assert np.count_nonzero(got[..., 3]) == 0
+    # the gradient spans ~6 decades (1/(x+1e-6) on near-black pixels): compare in the max-norm and in L2
+    assert U.rel_err(got, ref) < 2e-3
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-3
+
+
+def test_histogram_model_train_step_matches_oracle():
+    B, S = 2, 64
+    rng, Gp, Dp, src, tgt, masks = setup_case(B, S, 34)
+    tm = [torch.tensor(m, dtype=F64) for m in masks]
+    ref = rg.train_step_rgba(Gp, Dp, torch.tensor(src, dtype=F64), torch.tensor(tgt, dtype=F64), tm, lambda_l1=30.0,
+                             lambda_hist=1.0)
+    eng = E.Pix2PixEngine(4, 4, "tanh", S, L.F32)
+    eng.set_params(to_np(Gp), to_np(Dp))
+    out = eng.train_step_rgba(src, tgt, 30.0, lambda_hist=1.0, masks=masks, apply_update=False).cpu().numpy()
+    g, d = ref["g_loss"], ref["d_loss"]
+    want = np.array([g[0], g[1], g[2], g[3], d[0], d[1], d[2]])
+    print("losses", out, want)
+    for i in range(7):
+        assert abs(out[i] - want[i]) <= 1e-4 * abs(want[i]), (i, out[i], want[i])
+    wg = grad_report(eng.G.export(eng.G.grads), ref["g_grads"])
+    print("worst G grad", wg)
+    assert wg[1][1] < 2e-3          # L2; the histogram gradient's dynamic range makes ReLU-flip outliers likelier
+
+
+def test_argmax_is_bit_exact_with_engineered_ties():
+    rng = np.random.default_rng(35)
+    M, Cn = 4096, 256
+    p = rng.random((M, Cn)).astype(np.float32)
+    p /= p.sum(1, keepdims=True)
+    for r in range(0, M, 7):                     # exact ties, the winner must be the lowest index
+        i, j = sorted(rng.choice(Cn, 2, replace=False))
+        p[r, i] = p[r, j] = p[r].max() * 1.5
+    p[5, :] = 1.0 / Cn                            # fully uniform row -> index 0
+    got = torch.empty(M, dtype=torch.int32, device=U.DEV)
+    L.call("p2p_argmax_lastdim", U.ptr(U.dev(p)), M, Cn, U.ptr(got), U.stream())
+    want = torch.argmax(torch.tensor(p), dim=-1).to(torch.int32).numpy()      # tf.argmax semantics: first maximum
+    want_np = np.argmax(p, axis=-1).astype(np.int32)
+    assert np.array_equal(want, want_np)
+    assert np.array_equal(got.cpu().numpy(), want_np)
+    assert got[5].item() == 0
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_softmax_cce_argmax_kernel(dtype):
+    rng = np.random.default_rng(36)
+    n, s, Cn = 2, 8, 256
+    z = U.q(rng.normal(size=(n, s, s, Cn)) * 3, dtype)
+    tgt = rng.integers(0, Cn, size=(n, s, s, 1)).astype(np.int32)
+    zb = E.DenseBuf(n, s, s, Cn, U.tdt(dtype), U.DEV)
+    zb.t.copy_(U.dev(z.reshape(-1, Cn), U.tdt(dtype)))
+    tb = U.halo_from(tgt.astype(np.float32), dtype)
+    fb = E.HaloBuf(n, s, s, 1, dtype, U.DEV)
+    dz = E.HaloBuf(n, s, s, Cn, dtype, U.DEV)
+    probs = torch.empty((n, s, s, Cn), dtype=torch.float32, device=U.DEV)
+    loss = torch.zeros(2, dtype=torch.float32, device=U.DEV)
+    inv = 1.0 / (n * s * s)
+    L.call("p2p_softmax_cce_argmax", dtype, n, s, s, Cn, C.byref(zb.view()), C.byref(tb.view()), C.byref(fb.view()),
+           0.5 * inv, inv, C.byref(dz.view()), U.ptr(probs), U.ptr(loss), U.stream())
+    zt = torch.tensor(z, dtype=F64, requires_grad=True)
+    seg = rg.categorical_crossentropy_from_logits(zt, torch.tensor(tgt))
+    p_ref = torch.softmax(zt, -1)
+    (0.5 * seg).backward()
+    assert abs(float(loss[0]) - float(seg)) < 1e-5 * float(seg)
+    onehot = np.eye(Cn)[tgt[..., 0]]
+    assert abs(float(loss[1]) - np.abs(onehot - p_ref.detach().numpy()).mean()) < 1e-5
+    assert U.rel_err(probs.cpu().numpy(), p_ref.detach().numpy()) < 1e-5
+    assert np.array_equal(U.halo_to_np(fb)[..., 0].astype(np.int64), np.argmax(probs.cpu().numpy(), -1))
+    assert U.rel_err(U.halo_to_np(dz), zt.grad.numpy()) < (1e-5 if dtype == L.F32 else 6e-3)
+
+
+def test_indexed_model_train_step_matches_oracle():
+    B, S = 2, 64
+    rng = np.random.default_rng(37)
+    Gp = rg.perturb_affine(rg.init_params(rg.generator_param_shapes(1, 256), rng, F64), rng)
+    Dp = rg.perturb_affine(rg.init_params(rg.discriminator_param_shapes(1), rng, F64), rng)
+    # index inputs are un-normalised (0..255): scale the first-layer kernels so the test is not saturated
+    Gp["down1.kernel"] *= 0.05
+    Dp["down.kernel"] *= 0.05
+    src, tgt, _pal = rg.synthetic_indexed_batch(rng, B, S)
+    masks = [rng.integers(0, 2, size=s).astype(np.uint8) for s in rg.dropout_mask_shapes(B, S)]
+    ref = rg.train_step_indexed(Gp, Dp, torch.tensor(src), torch.tensor(tgt), [torch.tensor(m, dtype=F64) for m in masks], 0.01)
+    eng = E.Pix2PixEngine(1, 256, "softmax", S, L.F32)
+    eng.set_params(to_np(Gp), to_np(Dp))
+    out = eng.train_step_indexed(src, tgt, 0.01, masks=masks, apply_update=False).cpu().numpy()
+    g, d = ref["g_loss"], ref["d_loss"]
+    want = np.array([g[0], g[1], g[2], g[3], d[0], d[1], d[2]])
+    print("losses", out, want)
+    for i in range(7):
+        assert abs(out[i] - want[i]) <= 1e-4 * abs(want[i]), (i, out[i], want[i])
+    wg = grad_report(eng.G.export(eng.G.grads), ref["g_grads"])
+    wd = grad_report(eng.D.export(eng.D.grads), ref["d_grads"])
+    print("worst G", wg, "worst D", wd)
+    assert wg[1][1] < 2e-3 and wd[1][1] < 1e-4
+    # the generated index image is the argmax of the oracle's probabilities wherever that argmax is not a near-tie
+    idx = eng.generate_indexed(src, masks=masks).cpu().numpy()
+    pr = ref["probs"].numpy()
+    top2 = np.sort(pr, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-5
+    assert np.array_equal(idx[..., 0][clear], ref["fake_idx"].numpy()[..., 0][clear])
+    assert clear.mean() > 0.99
