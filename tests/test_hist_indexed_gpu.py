@@ -28,7 +28,7 @@ def test_rgbuv_histogram_forward_matches_oracle():
         ref = rg.rgbuv_histogram(torch.tensor(img, dtype=F64)).numpy()
         assert got.shape == (3, 64, 64, 3)
         np.testing.assert_allclose(got.sum(axis=(1, 2, 3)), 1.0, rtol=1e-5)
-        assert U.rel_err(got, ref) < 2e-5
+        assert U.rel_err(got, ref) < 1e-4       # f32 logf / division vs the f64 oracle (north_star tolerance 1e-4)
     # all-transparent image: three identical planes, the four centre bins are the equal maxima
     h = eng.rgbuv_histogram(np.full((1, 64, 64, 4), -1.0, np.float32)).cpu().numpy()[0]
     assert np.allclose(h[..., 0], h[..., 1]) and np.allclose(h[..., 0], h[..., 2])
@@ -46,7 +46,7 @@ def test_histogram_tail_batches_small_image():
     out = torch.empty((2, 64, 64, 3), dtype=torch.float32, device=U.DEV)
     L.call("p2p_hist_normalize", U.ptr(raw), 2, U.ptr(out), U.stream())
     ref = npr.rgbuv_histogram(img.astype(np.float64))
-    assert U.rel_err(out.cpu().numpy(), ref) < 2e-5
+    assert U.rel_err(out.cpu().numpy(), ref) < 1e-4
 
 
 @pytest.mark.parametrize("size", [8, 64])
