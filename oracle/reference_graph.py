@@ -331,8 +331,8 @@ def train_step_rgba(Gp, Dp, source, real, masks, lambda_l1, lambda_hist=None, gl
     d_grads = torch.autograd.grad(d_total, list(Dl.values()), allow_unused=True)                      # :79
     zg = lambda g, x: torch.zeros_like(x) if g is None else g
     return dict(
-        g_loss=tuple(float(x) for x in g_loss),
-        d_loss=(float(d_total), float(d_real), float(d_fake)),
+        g_loss=tuple(float(x.detach()) for x in g_loss),
+        d_loss=(float(d_total.detach()), float(d_real.detach()), float(d_fake.detach())),
         g_grads=OrderedDict((k, zg(g, Gl[k]).detach()) for k, g in zip(Gl, g_grads)),
         d_grads=OrderedDict((k, zg(g, Dl[k]).detach()) for k, g in zip(Dl, d_grads)),
         fake=fake.detach(), real_pred=real_pred.detach(), fake_pred=fake_pred.detach())
@@ -364,8 +364,8 @@ def train_step_indexed(Gp, Dp, source_idx, real_idx, masks, lambda_segmentation)
     d_grads = torch.autograd.grad(d_total, list(Dl.values()), allow_unused=True)
     zg = lambda g, x: torch.zeros_like(x) if g is None else g
     return dict(
-        g_loss=(float(g_total), float(adv), float(l1), float(seg)),
-        d_loss=(float(d_total), float(d_real), float(d_fake)),
+        g_loss=(float(g_total.detach()), float(adv.detach()), float(l1.detach()), float(seg.detach())),
+        d_loss=(float(d_total.detach()), float(d_real.detach()), float(d_fake.detach())),
         g_grads=OrderedDict((k, zg(g, Gl[k]).detach()) for k, g in zip(Gl, g_grads)),
         d_grads=OrderedDict((k, zg(g, Dl[k]).detach()) for k, g in zip(Dl, d_grads)),
         fake_idx=fake_idx.to(torch.int32), probs=probs.detach(), logits=logits.detach(),

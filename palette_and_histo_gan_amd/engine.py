@@ -734,6 +734,19 @@ class Pix2PixEngine:
         self.step_count += 1
         return torch.stack([g_total, g_adv, l1, seg, l[0] + l[1], l[0], l[1]])
 
+    def discriminate(self, target, source):
+        """discriminator([target, source], training=True) (pix2pix_model.py:69-70): f32 device logits (B,S/2,S/2,1)."""
+        B = int(target.shape[0])
+        P = self.plan(B)
+        S, ic, h2 = self.S, self.in_ch, self.S // 2
+        is_int = self.head == "softmax"
+        self._pack(P, self._to_device(target, ic, B, is_int), P["dcat"].view(coff=0), ic)
+        self._pack(P, self._to_device(source, ic, B, is_int), P["dcat"].view(coff=ic), ic)
+        self.discriminator_forward(P, B)
+        out = torch.empty((B, h2, h2, 1), dtype=torch.float32, device=self.device)
+        L.call("p2p_unpack", self.dtype, B, h2, h2, 1, C.byref(P["logits"].view()), _p(out), _stream())
+        return out
+
     def generate_indexed(self, source_idx, masks=None, with_probs=False):
         """Pix2PixIndexedModel.generate / generate_with_probs (pix2pix_model.py:283-293): int32 (B,S,S,1) argmax indices
         (and the f32 (B,S,S,256) probabilities)."""

@@ -1,0 +1,142 @@
+"""-m gpu: the reference-API model classes driven like experiments.ipynb drives them, the golden vectors through the
+engine, and the 2-rank data-parallel step (gloo transport, both ranks on the one GPU of the test box)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import reference_graph as rg
+from palette_and_histo_gan_amd import _lib as L
+from palette_and_histo_gan_amd import dataset_utils as D
+from palette_and_histo_gan_amd import engine as E
+from palette_and_histo_gan_amd import parallel as PAR
+from palette_and_histo_gan_amd import pix2pix_model as M
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F64 = torch.float64
+
+
+def test_fit_loop_runs_like_the_notebook(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    train = D.synthetic_rgba_ds(10, batch_size=4)          # 4 + 4 + 2: the ragged tail batch of the reference
+    test = D.synthetic_rgba_ds(6, batch_size=4, seed=3)
+    model = M.Pix2PixModel(train, test, "front2right", "pix2pix-test", lambda_l1=100.0)
+    assert model.generator.count_params() == 29_307_844 and model.discriminator.count_params() == 9_217
+    w0 = model.generator.trainable_variables[0].clone()
+    model.fit(7, 3, callbacks=["show_discriminator_output", "evaluate_fid", "evaluate_l1"])
+    assert model.engine.G.t == 7 and not torch.equal(w0, model.generator.trainable_variables[0])
+    assert len(model.checkpoint_manager.saved) == 1 and os.path.exists(model.checkpoint_manager.saved[0])
+    rows = [r for r in open(model.summary_writer.path)]
+    assert any("generator/l1_loss" in r for r in rows) and any("l1_evaluation/test" in r for r in rows)
+    g_loss, d_loss = model.train_step(next(iter(train)), 7, 3)
+    assert len(g_loss) == 3 and len(d_loss) == 3 and all(torch.isfinite(x) for x in g_loss + d_loss)
+    fake = model.generate(next(iter(test)))
+    assert tuple(fake.shape) == (4, 64, 64, 4) and float(fake.abs().max()) <= 1.0
+    logits = model.discriminator([next(iter(test))[1], next(iter(test))[0]], training=True)
+    assert tuple(logits.shape) == (4, 32, 32, 1)
+
+
+def test_histogram_and_indexed_models_train(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    train, test = D.synthetic_rgba_ds(8, batch_size=4, palette_size=24), D.synthetic_rgba_ds(4, batch_size=4, seed=5)
+    hm = M.Pix2PixHistogramModel(train, test, "front2right", "pix2pix-hist-test", lambda_l1=30.0, lambda_histogram=1.0)
+    hm.fit(3, 2)
+    g_loss, d_loss = hm.train_step(next(iter(train)), 3, 2)
+    assert len(g_loss) == 4 and float(g_loss[3]) > 0 and all(torch.isfinite(x) for x in g_loss)
+    itrain, itest = D.synthetic_indexed_ds(8, batch_size=4), D.synthetic_indexed_ds(4, batch_size=4, seed=6)
+    im = M.Pix2PixIndexedModel(itrain, itest, "front2right", "pix2pix-idx-test", lambda_segmentation=0.01)
+    assert im.generator.count_params() == 29_437_888 and im.discriminator.count_params() == 3_073
+    im.fit(3, 2)
+    g_loss, d_loss = im.train_step(next(iter(itrain)), 3, 2)
+    assert len(g_loss) == 4 and all(torch.isfinite(x) for x in g_loss + d_loss)
+    idx, probs = im.generate_with_probs(next(iter(itest)))
+    assert idx.dtype == torch.int32 and tuple(idx.shape) == (4, 64, 64, 1) and tuple(probs.shape) == (4, 64, 64, 256)
+    assert torch.equal(idx[..., 0].long(), torch.argmax(probs, -1))          # palette-index argmax, bit-exact
+    np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
+def test_engine_reproduces_golden_vectors():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"))
+    for tag, seed, l1, lh in (("baseline", 101, 100.0, None), ("histogram", 102, 30.0, 1.0)):
+        Gp, Dp, src, tgt, masks = mg.rgba_case(seed, l1, lh)
+        eng = E.Pix2PixEngine(4, 4, "tanh", 64, L.F32)
+        eng.set_params({k: v.numpy() for k, v in Gp.items()}, {k: v.numpy() for k, v in Dp.items()})
+        out = eng.train_step_rgba(src, tgt, l1, lambda_hist=lh, masks=masks, apply_update=False).cpu().numpy()
+        g, d = gold[f"{tag}.g_loss"], gold[f"{tag}.d_loss"]
+        want = [g[0], g[1], g[2], g[3] if lh else 0.0, d[0], d[1], d[2]]
+        for i in range(7):
+            assert abs(out[i] - want[i]) <= 1e-4 * abs(want[i]) + 1e-12, (tag, i, out[i], want[i])
+        grads = eng.G.export(eng.G.grads)
+        for k, a in grads.items():
+            a = a.reshape(-1).astype(np.float64)
+            samples = gold[f"{tag}.G.{k}.samples"]
+            got = a[mg.sample_positions(k, a.size)]
+            scale = gold[f"{tag}.G.{k}.abssum"] / a.size + 1e-30
+            assert np.abs(got - samples).max() < 2e-2 * max(np.abs(samples).max(), scale), (tag, k)
+            assert abs(np.abs(a).sum() - gold[f"{tag}.G.{k}.abssum"]) <= 1e-3 * gold[f"{tag}.G.{k}.abssum"] + 1e-12, (tag, k)
+    # argmax fixture, bit-exact
+    p = torch.as_tensor(gold["argmax.probs"]).to("cuda:0")
+    out = torch.empty(p.shape[0], dtype=torch.int32, device="cuda:0")
+    import ctypes as C
+    L.call("p2p_argmax_lastdim", C.c_void_p(p.data_ptr()), p.shape[0], p.shape[1], C.c_void_p(out.data_ptr()),
+           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert np.array_equal(out.cpu().numpy(), gold["argmax.index"])
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    comm = PAR.DataParallel("cuda:0", backend="gloo")
+    rng = np.random.default_rng(51)
+    Gp = rg.perturb_affine(rg.init_params(rg.generator_param_shapes(4, 4), rng, F64), rng)
+    Dp = rg.perturb_affine(rg.init_params(rg.discriminator_param_shapes(4), rng, F64), rng)
+    B = 4
+    src, tgt = rg.synthetic_rgba_batch(rng, B, 64, palette_size=24)
+    masks = [rng.integers(0, 2, size=s).astype(np.uint8) for s in rg.dropout_mask_shapes(B, 64)]
+    lo, hi = PAR.shard_bounds(B, world, rank)
+    eng = E.Pix2PixEngine(4, 4, "tanh", 64, L.F32, device="cuda:0")
+    eng.set_params({k: v.numpy() for k, v in Gp.items()}, {k: v.numpy() for k, v in Dp.items()})
+    out = eng.train_step_rgba(src[lo:hi], tgt[lo:hi], 30.0, lambda_hist=1.0, masks=[m[lo:hi] for m in masks],
+                              global_batch=B, allreduce=comm.allreduce_grads, hist_allreduce=comm.allreduce_scalar_sum)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((out.cpu().numpy(), eng.G.grads.cpu().numpy(), eng.D.grads.cpu().numpy(), eng.G.params.cpu().numpy()))
+    comm.barrier()
+    comm.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_engine_step_equals_single_rank_global_batch():
+    """SURVEY.md 8e equivalence test on the real kernels: 2 ranks x 2 images (histogram model: includes the Hellinger
+    scalar exchange) == 1 rank x 4 images; f32, tolerance 1e-5 of each tensor's max-norm on gradients."""
+    world, port = 2, 29641
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out2, g2, d2, p2 = q.get(timeout=800)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(51)
+    Gp = rg.perturb_affine(rg.init_params(rg.generator_param_shapes(4, 4), rng, F64), rng)
+    Dp = rg.perturb_affine(rg.init_params(rg.discriminator_param_shapes(4), rng, F64), rng)
+    src, tgt = rg.synthetic_rgba_batch(rng, 4, 64, palette_size=24)
+    masks = [rng.integers(0, 2, size=s).astype(np.uint8) for s in rg.dropout_mask_shapes(4, 64)]
+    eng = E.Pix2PixEngine(4, 4, "tanh", 64, L.F32)
+    eng.set_params({k: v.numpy() for k, v in Gp.items()}, {k: v.numpy() for k, v in Dp.items()})
+    out1 = eng.train_step_rgba(src, tgt, 30.0, lambda_hist=1.0, masks=masks).cpu().numpy()
+    np.testing.assert_allclose(out2, out1, rtol=2e-6)
+    g1, d1 = eng.G.grads.cpu().numpy(), eng.D.grads.cpu().numpy()
+    assert np.abs(g2 - g1).max() <= 1e-5 * np.abs(g1).max()
+    assert np.abs(d2 - d1).max() <= 1e-5 * np.abs(d1).max()
+    # identical Adam update on every rank (no parameter broadcast needed after step 0)
+    assert np.abs(p2 - eng.G.params.cpu().numpy()).max() < 1e-6
