@@ -673,7 +673,9 @@ class Pix2PixEngine:
                _p(P["h_sq"]), _stream())
         if hist_allreduce is not None:
             hist_allreduce(P["h_sq"][:1])
-        L.call("p2p_hellinger_finish", _p(P["h_sq"]), 1.0 / Bg, _p(self.losses, 4), _stream())
+        # every rank holds the GLOBAL loss after the exchange; it records its B/Bg share so that the SUM all-reduce
+        # of the loss scalars (like the element-mean losses) yields the global value
+        L.call("p2p_hellinger_finish", _p(P["h_sq"]), (1.0 / Bg) * (B / Bg), _p(self.losses, 4), _stream())
         coef = float(lambda_hist) / (2.0 * math.sqrt(2.0) * Bg)
         L.call("p2p_rgbuv_hist_hellinger_bwd", self.dtype, B, S, S, C.byref(fake_view), _p(P["h_real"]), _p(P["h_fake"]),
                _p(P["h_tot"][0]), _p(P["h_tot"][1]), _p(P["h_sq"]), coef, _p(P["h_gh"]), _p(P["h_dimg"]), _stream())

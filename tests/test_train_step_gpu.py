@@ -97,10 +97,17 @@ def test_train_step_bf16_matches_bf16_storage_oracle(use_mfma):
 
 
 def test_two_adam_steps_match_oracle_f32():
+    """Two consecutive steps (Adam t = 1, 2; weight copies refreshed in between).  The step-2 losses depend on every
+    updated weight and must match to 1e-4.  Per-entry comparison of the weights is ill-posed for entries whose
+    gradient is at rounding level (Adam moves them by ~lr * sign(g)), so the update DIRECTION of each tensor is
+    compared instead (cosine of the accumulated update) plus its magnitude."""
     B, S = 2, 64
     rng, Gp, Dp, src, tgt, masks = setup_case(B, S, 22)
     eng = E.Pix2PixEngine(4, 4, "tanh", S, L.F32)
     eng.set_params(to_np(Gp), to_np(Dp))
+    f32 = lambda v: v.numpy().astype(np.float32).astype(np.float64)      # what the engine's f32 masters hold
+    start = dict({k: v.numpy().copy() for k, v in Gp.items()}, **{"D." + k: v.numpy().copy() for k, v in Dp.items()})
+    start32 = dict({k: f32(v) for k, v in Gp.items()}, **{"D." + k: f32(v) for k, v in Dp.items()})
     gm, gv, dm, dv = (rg.zeros_like_params(Gp), rg.zeros_like_params(Gp), rg.zeros_like_params(Dp), rg.zeros_like_params(Dp))
     tm = [torch.tensor(m, dtype=F64) for m in masks]
     for t in (1, 2):
@@ -110,18 +117,17 @@ def test_two_adam_steps_match_oracle_f32():
         out = eng.train_step_rgba(src, tgt, 100.0, masks=masks).cpu().numpy()
         assert abs(out[0] - ref["g_loss"][0]) < 1e-4 * abs(ref["g_loss"][0]), t
         assert abs(out[4] - ref["d_loss"][0]) < 1e-4 * abs(ref["d_loss"][0]), t
-        got = dict(eng.G.export(), **{"D." + k: v for k, v in eng.D.export().items()})
-        want = dict({k: v for k, v in Gp.items()}, **{"D." + k: v for k, v in Dp.items()})
-        grads = dict(ref["g_grads"], **{"D." + k: v for k, v in ref["d_grads"].items()})
-        for k in want:
-            g = grads[k].numpy()
-            # Adam's first steps move every weight by ~lr*sign(g): entries whose gradient is at rounding level
-            # have no defined sign, so compare the entries with a significant gradient; 2% of lr = 4e-6
-            sig = np.abs(g) > 1e-2 * np.abs(g).max() if np.abs(g).max() > 0 else np.ones_like(g, bool)
-            # (a ReLU input ~1e-6 from zero may flip between f64 and f32 and move a handful of entries, and at t=2
-            #  entries with g1 ~ -g2 are ill-conditioned: allow 1% of them; the step-2 losses above are the strong check)
-            bad = np.abs(got[k] - want[k].numpy())[sig] >= 4e-6 * t
-            assert bad.sum() <= max(2, 1e-2 * bad.size), (t, k, int(bad.sum()), bad.size)
+    assert eng.G.t == 2 and eng.D.t == 2
+    got = dict(eng.G.export(), **{"D." + k: v for k, v in eng.D.export().items()})
+    want = dict({k: v.numpy() for k, v in Gp.items()}, **{"D." + k: v.numpy() for k, v in Dp.items()})
+    for k in want:
+        du_ref, du_got = (want[k] - start[k]).ravel(), (got[k] - start32[k]).ravel().astype(np.float64)
+        if np.abs(du_ref).max() == 0.0:          # down6.kernel / down6.gamma: dead at S=64
+            assert np.abs(du_got).max() == 0.0, k
+            continue
+        cos = float(du_ref @ du_got / (np.linalg.norm(du_ref) * np.linalg.norm(du_got)))
+        assert cos > 0.995, (k, cos)
+        assert abs(np.linalg.norm(du_got) / np.linalg.norm(du_ref) - 1.0) < 1e-2, k
 
 
 def test_generate_is_forward_of_train_step():
