@@ -88,6 +88,8 @@ def kernel_profile(eng, run_step, n_steps=3):
 
     L.call = timed
     E.L.call = timed
+    side_was = eng.side.enabled
+    eng.side.enabled = False          # serialise everything on the launch stream so that each event pair brackets its kernel
     try:
         for _ in range(n_steps):
             run_step()
@@ -95,6 +97,7 @@ def kernel_profile(eng, run_step, n_steps=3):
     finally:
         L.call = orig
         E.L.call = orig
+        eng.side.enabled = side_was
     agg = {}
     for name, args, a, b in records:
         key = name
@@ -115,6 +118,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-mfma", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph (N=1 only uses graphs)")
     ap.add_argument("--detail", default=None, help="write a per-call (entry point, shape) device-time table to this file")
     args = ap.parse_args()
 
@@ -137,8 +141,20 @@ def main():
     tgt_d = torch.as_tensor(tgt).to(device)
     allreduce = comm.allreduce_grads if comm is not None else None
 
-    def run_step():
-        return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, allreduce=allreduce)
+    hist_allreduce = comm.allreduce_scalar_sum if comm is not None else None
+
+    def run_step_eager():
+        return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, allreduce=allreduce,
+                                   hist_allreduce=hist_allreduce)
+
+    use_graph = world == 1 and not args.no_graph
+    if use_graph:
+        graphed = eng.graphed_rgba_step(B, lam_l1, lam_hist, global_batch=B)
+
+        def run_step():
+            return graphed(src_d, tgt_d)
+    else:
+        run_step = run_step_eager
 
     for _ in range(args.warmup):
         run_step()
@@ -164,7 +180,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.config}: {model} Pix2Pix train step, per-GPU batch {B}, {S}x{S} RGBA sprites, "
                                f"lambda_l1={lam_l1}" + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
-                   "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}"},
+                   "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if use_graph else "eager"},
         "losses": [round(float(x), 5) for x in losses.cpu().numpy()],
     }
 
@@ -173,7 +190,7 @@ def main():
         result["conv_tflops"] = round(flops_img * value / 1e12, 2)
         result["conv_mfma_frac_of_peak"] = round(flops_img * value / 1e12 / (MFMA_PEAK[args.dtype] * world), 4)
         if not args.no_profile:
-            prof, records = kernel_profile(eng, run_step)
+            prof, records = kernel_profile(eng, run_step_eager)
             result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype, MFMA_PEAK[args.dtype])
             if args.detail:

@@ -114,21 +114,24 @@ int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, 
  * gamma/beta null => no normalisation (down1, D.down: networks.py:46,58).
  * y = act(drop(gamma*(x-mu)*rsqrt(var+eps)+beta)), dropout keep-mask `mask` (u8 dense [N*H*W][C], may be
  * null) scales kept values by 2.  Writes y into the (haloed, possibly channel-sliced) view `out`,
- * mean/rstd into stats[N][C][2] and, if raw_out != null, the summed raw tensor in `dtype`. */
+ * mean/rstd into stats[N][C][2] and, if raw_out != null, the summed raw tensor in `dtype`.
+ * nsplit > 1 splits every image's pixel range over nsplit workgroups (two launches: partial sums to the f32
+ * workspace ws, >= N*nsplit*C*2*4 bytes, then apply); nsplit <= 1 or ws == null = one launch. */
 int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C,
                      const void* raw, int raw_kind, int nslabs, long long slab_stride,
                      const float* gamma, const float* beta, float eps, int act, float alpha,
                      const unsigned char* mask, const p2p_tensor* out, void* raw_out, float* stats,
-                     void* stream);
+                     float* ws, long long ws_bytes, int nsplit, void* stream);
 
 /* Backward of the fused block: dact = g1 + g2 (pointwise gradient sources), through dropout/activation
  * (sign recomputed from raw+stats) and the InstanceNorm closed form.  Writes d(raw)
- * into the haloed view `draw` and per-image partials dgamma_part/dbeta_part [N][C] (f32). */
+ * into the haloed view `draw` and per-image partials dgamma_part/dbeta_part [N][C] (f32).  ws/nsplit as above. */
 int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C,
                      const void* raw, const float* stats, const float* gamma, const float* beta,
                      int act, float alpha, const unsigned char* mask,
                      const p2p_gsrc* g1, const p2p_gsrc* g2,
-                     const p2p_tensor* draw, float* dgamma_part, float* dbeta_part, void* stream);
+                     const p2p_tensor* draw, float* dgamma_part, float* dbeta_part,
+                     float* ws, long long ws_bytes, int nsplit, void* stream);
 
 /* Backward of a LeakyReLU that was fused into a conv epilogue (only its OUTPUT is stored):
  * draw = (g1 + g2) * (act_out > 0 ? 1 : alpha). */
@@ -203,6 +206,13 @@ int p2p_argmax_lastdim(const float* probs, long long M, int C, int* out, void* s
 int p2p_adam_flat(float* p, const float* g, float* m, float* v, long long n, int t,
                   float lr, float beta1, float beta2, float eps, float gscale, void* stream);
 
+/* Device-resident step state (lets a whole step be captured in a hipGraph and replayed): t_dev[0] += 1 and
+ * lr_t_dev[0] = lr*sqrt(1-beta2^t)/(1-beta1^t); p2p_adam_flat_dev reads the step size from lr_t_dev. */
+int p2p_adam_tick(int* t_dev, float* lr_t_dev, float lr, float beta1, float beta2, void* stream);
+int p2p_adam_flat_dev(float* p, const float* g, float* m, float* v, long long n, const float* lr_t_dev,
+                      float beta1, float beta2, float eps, float gscale, void* stream);
+int p2p_counter_add(long long* counter_dev, long long inc, void* stream);
+
 /* master f32 W[16][Cg][Cd] -> wn (dtype, same layout; may be null) and wt (dtype, [16][Cd][Cg]; may be null). */
 int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* wn, void* wt, void* stream);
 
@@ -219,6 +229,9 @@ int p2p_unpack(int dtype, int N, int H, int W, int C, const p2p_tensor* src, flo
 
 /* Bernoulli(0.5) keep mask of Dropout(0.5) (networks.py:31-32): counter-based RNG, one byte per element. */
 int p2p_dropout_mask(unsigned char* mask, long long n, long long seed, long long counter, void* stream);
+/* same with the call counter = counter_dev[0]*16 + salt read on the device. */
+int p2p_dropout_mask_dev(unsigned char* mask, long long n, long long seed, const long long* counter_dev,
+                         long long salt, void* stream);
 
 #ifdef __cplusplus
 }

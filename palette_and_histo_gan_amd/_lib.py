@@ -36,14 +36,18 @@ SIGNATURES = {
     "p2p_act_bwd": [_i, _i, _i, _i, _i, _TP, _GP, _GP, _f, _TP, _vp],
     "p2p_weight_prep_pad": [_i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "p2p_wgemm": [_i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
-    "p2p_norm_act_fwd": [_i, _i, _i, _i, _i, _vp, _i, _i, _ll, _vp, _vp, _f, _i, _f, _vp, _TP, _vp, _vp, _vp],
-    "p2p_norm_act_bwd": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _GP, _GP, _TP, _vp, _vp, _vp],
+    "p2p_norm_act_fwd": [_i, _i, _i, _i, _i, _vp, _i, _i, _ll, _vp, _vp, _f, _i, _f, _vp, _TP, _vp, _vp, _vp, _ll, _i, _vp],
+    "p2p_norm_act_bwd": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _GP, _GP, _TP, _vp, _vp, _vp, _ll, _i, _vp],
     "p2p_colsum": [_vp, _i, _i, _f, _vp, _vp],
     "p2p_colsum_batched": [_vp, _vp, _i, _i, _vp, _vp],
     "p2p_bce_logits": [_i, _i, _i, _i, _i, _TP, _f, _TP, _TP, _vp, _vp],
     "p2p_tanh_l1_fwd": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp],
     "p2p_tanh_l1_bwd": [_i, _i, _i, _i, _i, _TP, _TP, _GP, _GP, _f, _TP, _vp],
     "p2p_adam_flat": [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp],
+    "p2p_adam_tick": [_vp, _vp, _f, _f, _f, _vp],
+    "p2p_adam_flat_dev": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp],
+    "p2p_counter_add": [_vp, _ll, _vp],
+    "p2p_dropout_mask_dev": [_vp, _ll, _ll, _vp, _ll, _vp],
     "p2p_weight_prep": [_i, _vp, _i, _i, _vp, _vp, _vp],
     "p2p_pack_input": [_i, _i, _i, _i, _i, _vp, _i, _TP, _vp],
     "p2p_unpack": [_i, _i, _i, _i, _i, _TP, _vp, _vp],

@@ -53,7 +53,7 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T, int WM, int WN, int TM, int TN, bool GEN>
+template <typename T, int WM, int WN, int TM, int TN, bool GEN, bool VEPI>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -69,10 +69,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     const int tap_begin = ks * a.taps_per;
     const int CBbytes = GEN ? a.Cc * 16 : (1 << a.lgCB);          // bytes per tap row
     const int nkb = (a.taps_per * CBbytes) >> 7;                  // K-blocks of 128 bytes
-    const long long esz = sizeof(T);
+    constexpr int esz = sizeof(T);
+    const int pixB = a.in_ld * esz, rowB = a.in_row * pixB;       // byte strides of the gathered view
 
     // ---- per-thread staging rows -------------------------------------------------------------------
-    long long abase[NA];   // byte offset of the row's base pixel in the input view
+    const char* abase[NA];   // address of the row's base pixel in the input view
     int aq[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -83,18 +84,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         int n = m >> (a.lgLW + a.lgLH);
         int by = a.mode == 0 ? a.si * y - 1 : y;
         int bx = a.mode == 0 ? a.si * x - 1 : x;
-        abase[i] = ((long long)n * a.in_img + (long long)by * a.in_row + bx) * a.in_ld * esz;
+        abase[i] = a.in + ((long long)n * a.in_img + (long long)by * a.in_row + bx) * pixB;
         aq[i] = (lane & 7) ^ ((r >> 1) & 7);
     }
     int bq[NB];
-    long long bbase[NB];
+    int bbase[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         int r = (j * 4 + wave) * 8 + (lane >> 3);
         bq[j] = (lane & 7) ^ ((r >> 1) & 7);
-        bbase[j] = (long long)(n0 + r) * a.C * esz;
+        bbase[j] = (n0 + r) * a.C * esz;
     }
-    const long long wtap = (long long)a.w_rows * a.C * esz;   // bytes per weight tap slab
+    const int wtap = a.w_rows * a.C * esz;   // bytes per weight tap slab
 
     auto tap_geom = [&](int tl, int& dy, int& dx, int& widx) {
         if (a.mode == 0) { dy = tl >> 2; dx = tl & 3; widx = tl; }
@@ -122,19 +123,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             int tl, cbyte, dy, dx, widx;
             split_k(kb, aq[i], tl, cbyte);
             tap_geom(tl, dy, dx, widx);
-            const char* src = a.in + abase[i] + ((long long)dy * a.in_row + dx) * a.in_ld * esz + cbyte;
-            glds16(src, buf + (i * 4 + wave) * 1024);
+            glds16(abase[i] + (dy * rowB + dx * pixB + cbyte), buf + (i * 4 + wave) * 1024);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int tl, cbyte, dy, dx, widx;
             split_k(kb, bq[j], tl, cbyte);
             tap_geom(tl, dy, dx, widx);
-            const char* src = a.w + widx * wtap + bbase[j] + cbyte;
-            glds16(src, buf + A_BYTES + (j * 4 + wave) * 1024);
+            glds16(a.w + (widx * wtap + bbase[j] + cbyte), buf + A_BYTES + (j * 4 + wave) * 1024);
         }
     };
 
+    // accumulators: weights are the MFMA "A" operand (rows = output channel), pixels the "B" operand
+    // (columns), so a lane ends up with 4 CONSECUTIVE output channels of one pixel per register group.
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -172,44 +173,90 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) mfma_step(acc[i][j], af[i], bf[j]);
+                for (int j = 0; j < TN; ++j) mfma_step(acc[i][j], bf[j], af[i]);
         }
     }
 
-    // ---- epilogue: D[row = m][col = n], col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -------------
-    float bcol[TN];
+    // ---- epilogue: D[row = n][col = m]: col = lane&31 (pixel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (channel) ----
+    auto out_pixel = [&](int m) -> long long {
+        int x = m & (a.LW - 1);
+        int y = (m >> a.lgLW) & (a.LH - 1);
+        int n = m >> (a.lgLW + a.lgLH);
+        if (a.mode == 1) return (long long)n * a.out_img + (long long)(2 * y + ph) * a.out_row + (2 * x + pw);
+        return (long long)n * a.out_img + (long long)y * a.out_row + x;
+    };
+    const bool to_slabs = a.splitk > 1;
+    if constexpr (VEPI) {
+        // stage the tile through LDS as [pixel][channel] in the OUTPUT type, then store whole 16-byte chunks of
+        // each pixel's channel run (coalesced rows instead of 2-byte scatter).
+        __syncthreads();      // every wave is done reading the operand tiles
+        auto run = [&](auto tag) {
+            typedef decltype(tag) TO;
+            constexpr int osz = sizeof(TO);
+            constexpr int RS = BN * osz + 16;     // padded row stride (16-byte aligned rows; the 32 pixel lanes' 4-channel writes hit distinct banks)
+            typedef __attribute__((__vector_size__(4 * sizeof(TO)))) TO vec4_t;
+            constexpr int CE = 16 / osz, CPR = BN / CE, RPP = 256 / CPR;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-        bcol[j] = (GEN && a.bias && col < a.ncols) ? a.bias[col] : 0.f;
-    }
+            for (int i = 0; i < TM; ++i) {
+                int ml = (wm * TM + i) * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+                for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m >= a.M) continue;
-            int x = m & (a.LW - 1);
-            int y = (m >> a.lgLW) & (a.LH - 1);
-            int n = m >> (a.lgLW + a.lgLH);
-            long long pix;
-            if (a.mode == 1) pix = (long long)n * a.out_img + (long long)(2 * y + ph) * a.out_row + (2 * x + pw);
-            else pix = (long long)n * a.out_img + (long long)y * a.out_row + x;
+                    for (int g = 0; g < 4; ++g) {
+                        int nl = (wn * TN + j) * 32 + 8 * g + 4 * h;
+                        vec4_t v4;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-                if (GEN && col >= a.ncols) continue;
-                float v = acc[i][j][e];
-                if (a.splitk == 1) {
-                    if (GEN) {
-                        v += bcol[j];
-                        if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
+                        for (int k = 0; k < 4; ++k) {
+                            float v = acc[i][j][4 * g + k];
+                            if (GEN && !to_slabs) {
+                                int col = n0 + nl + k;
+                                if (a.bias && col < a.ncols) v += a.bias[col];
+                                if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
+                            }
+                            v4[k] = from_f32<TO>(v);
+                        }
+                        *(vec4_t*)(smem + ml * RS + nl * osz) = v4;
                     }
-                    ((T*)a.out)[pix * a.out_ld + col] = from_f32<T>(v);
-                } else {
-                    a.slabs[(long long)ks * a.slab_stride + pix * a.out_ld + col] = v;
                 }
             }
+            __syncthreads();
+            TO* obase = to_slabs ? (TO*)(a.slabs + (long long)ks * a.slab_stride) : (TO*)a.out;
+            const int chunk = tid % CPR, r0 = tid / CPR;
+            const int col = n0 + chunk * CE;
+#pragma unroll
+            for (int ps = 0; ps < BM / RPP; ++ps) {
+                int ml = ps * RPP + r0;
+                int m = m0 + ml;
+                if (m < a.M && col < a.ncols) {
+                    f32x4 v = *(const f32x4*)(smem + ml * RS + chunk * 16);
+                    *(f32x4*)(obase + out_pixel(m) * a.out_ld + col) = v;
+                }
+            }
+        };
+        if (to_slabs) run(float()); else run(T());
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int m = m0 + (wm * TM + i) * 32 + (lane & 31);
+            if (m >= a.M) continue;
+            long long pix = out_pixel(m);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int col = n0 + (wn * TN + j) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (col >= a.ncols) continue;
+                    float v = acc[i][j][e];
+                    if (!to_slabs) {
+                        if (GEN) {
+                            if (a.bias) v += a.bias[col];
+                            if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
+                        }
+                        ((T*)a.out)[pix * a.out_ld + col] = from_f32<T>(v);
+                    } else {
+                        a.slabs[(long long)ks * a.slab_stride + pix * a.out_ld + col] = v;
+                    }
+                }
         }
     }
 }
@@ -220,23 +267,36 @@ static int ilog2_exact(long long v) {
     return (1LL << l) == v ? l : -1;
 }
 
+template <typename T, int WM, int WN, int TM, int TN, bool GEN>
+static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int ctiles = (a.ncols + 31) / 32 * 32;
+    dim3 grid((a.M + BM - 1) / BM, (ctiles + BN - 1) / BN, gz);
+    size_t stage = 2 * (size_t)(BM + BN) * 128;
+    size_t epi = (size_t)BM * (BN * 4 + 16);           // f32 staging of the epilogue is the larger case
+    size_t shm = vepi ? (stage > epi ? stage : epi) : stage;
+    static bool attr_done[2] = {false, false};      // per template instantiation: allow > 64 KB of dynamic LDS
+    if (!attr_done[vepi]) {
+        if (vepi) (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        else (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done[vepi] = true;
+    }
+    if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true><<<grid, dim3(256), shm, st>>>(a);
+    else igemm_kernel<T, WM, WN, TM, TN, GEN, false><<<grid, dim3(256), shm, st>>>(a);
+}
+
 template <typename T, bool GEN>
-static int igemm_launch(IgemmArgs& a, int phases, hipStream_t st) {
-    dim3 block(256);
+static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
     unsigned gz = (unsigned)(phases * a.splitk);
     const int ctiles = (a.ncols + 31) / 32 * 32;      // launched columns (<= w_rows)
-    if (ctiles % 128 == 0) {
-        constexpr int BM = 128, BN = 128;
-        dim3 grid((a.M + BM - 1) / BM, ctiles / BN, gz);
-        igemm_kernel<T, 2, 2, 2, 2, GEN><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
-    } else if (ctiles % 64 == 0) {
-        constexpr int BM = 128, BN = 64;
-        dim3 grid((a.M + BM - 1) / BM, ctiles / BN, gz);
-        igemm_kernel<T, 2, 2, 2, 1, GEN><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+    const bool bigM = a.M >= 256 * 512;                // enough rows to fill the chip with 256-row tiles
+    if (ctiles % 128 == 0) igemm_go<T, 2, 2, 2, 2, GEN>(a, gz, vepi, st);
+    else if (ctiles % 64 == 0) {
+        if (bigM) igemm_go<T, 4, 1, 2, 2, GEN>(a, gz, vepi, st);
+        else igemm_go<T, 2, 2, 2, 1, GEN>(a, gz, vepi, st);
     } else {
-        constexpr int BM = 128, BN = 32;
-        dim3 grid((a.M + BM - 1) / BM, ctiles / BN, gz);
-        igemm_kernel<T, 4, 1, 1, 1, GEN><<<grid, block, 2 * (BM + BN) * 128, st>>>(a);
+        if (bigM) igemm_go<T, 4, 1, 2, 1, GEN>(a, gz, vepi, st);
+        else igemm_go<T, 4, 1, 1, 1, GEN>(a, gz, vepi, st);
     }
     return p2p_check_launch("p2p_igemm");
 }
@@ -283,8 +343,12 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
     a.splitk = splitk;
     const int phases = a.mode == 1 ? 4 : 1;
     hipStream_t st = (hipStream_t)stream;
-    if (pow2) { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, false>(a, phases, st))); }
-    else { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, true>(a, phases, st))); }
+    // vector epilogue: whole 16-byte chunks of each pixel's channel run must be addressable
+    const int osz = splitk > 1 ? 4 : esz, ce = 16 / osz;
+    const bool vepi = ncols % ce == 0 && (a.out_ld * osz) % 16 == 0 &&
+                      (splitk > 1 ? ((uintptr_t)slabs % 16) == 0 : ((uintptr_t)out->ptr % 16) == 0);
+    if (pow2) { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, false>(a, phases, vepi, st))); }
+    else { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, true>(a, phases, vepi, st))); }
 }
 
 extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,

@@ -223,54 +223,86 @@ __device__ __forceinline__ void mask_vload8(const unsigned char* m, float* keep,
     }
 }
 
-template <typename T>
+// MODE 0: one launch per layer (statistics + apply, grid.z = 1 when normalising).
+// MODE 1 / 2: the pixel range of every image is split over grid.z workgroups; launch 1 writes per-split partial
+// sums to ws[N][SP][C][2], launch 2 adds them up (fixed order: deterministic) and applies.  Used when one workgroup
+// per (image, 64 channels) would leave most of the chip idle (64x64 maps with 32-64 channels).
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int CG, const void* __restrict__ raw,
                                                         int raw_kind, int nslabs, long long slab,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int act, float alpha,
                                                         const unsigned char* __restrict__ mask, TView out,
-                                                        T* __restrict__ raw_out, float* __restrict__ stats) {
+                                                        T* __restrict__ raw_out, float* __restrict__ stats,
+                                                        float* __restrict__ ws) {
     constexpr int VN = VecOf<T>::N;
-    __shared__ float red[2][256 * 8 / 8 * 8];      // [2][PR][CG] with PR*CG/VN*VN <= 2048
+    __shared__ float red[2][2048];      // [2][PR][CG], PR * CG = 256 * VN <= 2048
     const int n = blockIdx.x;
     const int cg0 = blockIdx.y * CG;
+    const int SP = gridDim.z, sp = blockIdx.z;
     const int VPP = CG / VN, PR = 256 / VPP;
     const int vid = threadIdx.x % VPP, pr = threadIdx.x / VPP;
     const int c = cg0 + vid * VN;
     const int HW = H * W;
+    const int chunk = (HW + SP - 1) / SP;
+    const int pb = sp * chunk, pe = min(HW, pb + chunk);
     const long long base = (long long)n * HW * C + c;
     float mu[VN], rs[VN], ga[VN], be[VN];
     if (gamma) {
-        float sh[VN], s1[VN], s2[VN];
-        raw_vload<T>(raw, raw_kind, nslabs, slab, base, sh);
+        float sh[VN], t1[VN], t2[VN];
+        raw_vload<T>(raw, raw_kind, nslabs, slab, base, sh);        // image-wide shift: the first pixel's value
+        if (MODE != 2) {
+            float s1[VN], s2[VN];
 #pragma unroll
-        for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
-        for (int p = pr; p < HW; p += PR) {
-            float x[VN];
-            raw_vload<T>(raw, raw_kind, nslabs, slab, base + (long long)p * C, x);
+            for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+            for (int p = pb + pr; p < pe; p += PR) {
+                float x[VN];
+                raw_vload<T>(raw, raw_kind, nslabs, slab, base + (long long)p * C, x);
 #pragma unroll
-            for (int k = 0; k < VN; ++k) { float d = x[k] - sh[k]; s1[k] += d; s2[k] += d * d; }
+                for (int k = 0; k < VN; ++k) { float d = x[k] - sh[k]; s1[k] += d; s2[k] += d * d; }
+            }
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                t1[k] = 0.f; t2[k] = 0.f;
+                for (int i = 0; i < PR; ++i) { t1[k] += red[0][i * CG + vid * VN + k]; t2[k] += red[1][i * CG + vid * VN + k]; }
+            }
+            if (MODE == 1) {
+                if (pr == 0)
+#pragma unroll
+                    for (int k = 0; k < VN; ++k) {
+                        ws[(((long long)n * SP + sp) * C + c + k) * 2 + 0] = t1[k];
+                        ws[(((long long)n * SP + sp) * C + c + k) * 2 + 1] = t2[k];
+                    }
+                return;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                t1[k] = 0.f; t2[k] = 0.f;
+                for (int i = 0; i < SP; ++i) {
+                    t1[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 0];
+                    t2[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 1];
+                }
+            }
         }
 #pragma unroll
-        for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
-        __syncthreads();
-#pragma unroll
         for (int k = 0; k < VN; ++k) {
-            float t1 = 0.f, t2 = 0.f;
-            for (int i = 0; i < PR; ++i) { t1 += red[0][i * CG + vid * VN + k]; t2 += red[1][i * CG + vid * VN + k]; }
-            float m = t1 / (float)HW;
-            float var = fmaxf(t2 / (float)HW - m * m, 0.f);
+            float m = t1[k] / (float)HW;
+            float var = fmaxf(t2[k] / (float)HW - m * m, 0.f);
             mu[k] = sh[k] + m;
             rs[k] = rsqrtf(var + eps);
             ga[k] = gamma[c + k];
             be[k] = beta[c + k];
-            if (pr == 0) {
+            if (pr == 0 && sp == 0) {
                 stats[((long long)n * C + c + k) * 2 + 0] = mu[k];
                 stats[((long long)n * C + c + k) * 2 + 1] = rs[k];
             }
         }
     }
-    for (int p = pr; p < HW; p += PR) {
+    for (int p = pb + pr; p < pe; p += PR) {
         long long e = base + (long long)p * C;
         float x[VN], keep[VN];
         raw_vload<T>(raw, raw_kind, nslabs, slab, e, x);
@@ -289,21 +321,24 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
     }
 }
 
-template <typename T>
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int CG, const T* __restrict__ raw,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int act, float alpha,
                                                         const unsigned char* __restrict__ mask, GSrc g1, GSrc g2,
                                                         TView draw, float* __restrict__ dgamma_part,
-                                                        float* __restrict__ dbeta_part) {
+                                                        float* __restrict__ dbeta_part, float* __restrict__ ws) {
     constexpr int VN = VecOf<T>::N;
     __shared__ float red[2][2048];
     const int n = blockIdx.x;
     const int cg0 = blockIdx.y * CG;
+    const int SP = gridDim.z, sp = blockIdx.z;
     const int VPP = CG / VN, PR = 256 / VPP;
     const int vid = threadIdx.x % VPP, pr = threadIdx.x / VPP;
     const int c = cg0 + vid * VN;
     const int HW = H * W;
+    const int chunk = (HW + SP - 1) / SP;
+    const int pb = sp * chunk, pe = min(HW, pb + chunk);
     const long long pix0 = (long long)n * HW;
     const long long base = pix0 * C + c;
     float mu[VN], rs[VN], ga[VN], be[VN];
@@ -334,31 +369,55 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
             d[k] = (a1[k] + a2[k]) * slope * kp;
         }
     };
-    float s1[VN], s2[VN];
+    float t1[VN], t2[VN];
+    if (MODE != 2) {
+        float s1[VN], s2[VN];
 #pragma unroll
-    for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
-    for (int p = pr; p < HW; p += PR) {
-        float d[VN], xh[VN];
-        dyhat(p, d, xh);
+        for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+        for (int p = pb + pr; p < pe; p += PR) {
+            float d[VN], xh[VN];
+            dyhat(p, d, xh);
 #pragma unroll
-        for (int k = 0; k < VN; ++k) { s1[k] += d[k]; s2[k] += d[k] * xh[k]; }
+            for (int k = 0; k < VN; ++k) { s1[k] += d[k]; s2[k] += d[k] * xh[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            t1[k] = 0.f; t2[k] = 0.f;
+            for (int i = 0; i < PR; ++i) { t1[k] += red[0][i * CG + vid * VN + k]; t2[k] += red[1][i * CG + vid * VN + k]; }
+        }
+        if (MODE == 1) {
+            if (pr == 0)
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    ws[(((long long)n * SP + sp) * C + c + k) * 2 + 0] = t1[k];
+                    ws[(((long long)n * SP + sp) * C + c + k) * 2 + 1] = t2[k];
+                }
+            return;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            t1[k] = 0.f; t2[k] = 0.f;
+            for (int i = 0; i < SP; ++i) {
+                t1[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 0];
+                t2[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 1];
+            }
+        }
     }
-#pragma unroll
-    for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
-    __syncthreads();
     float m1[VN], m2[VN];
 #pragma unroll
     for (int k = 0; k < VN; ++k) {
-        float t1 = 0.f, t2 = 0.f;
-        for (int i = 0; i < PR; ++i) { t1 += red[0][i * CG + vid * VN + k]; t2 += red[1][i * CG + vid * VN + k]; }
-        if (pr == 0) {
-            dbeta_part[(long long)n * C + c + k] = t1;
-            dgamma_part[(long long)n * C + c + k] = t2;
+        if (pr == 0 && sp == 0) {
+            dbeta_part[(long long)n * C + c + k] = t1[k];
+            dgamma_part[(long long)n * C + c + k] = t2[k];
         }
-        m1[k] = t1 / (float)HW;
-        m2[k] = t2 / (float)HW;
+        m1[k] = t1[k] / (float)HW;
+        m2[k] = t2[k] / (float)HW;
     }
-    for (int p = pr; p < HW; p += PR) {
+    for (int p = pb + pr; p < pe; p += PR) {
         float d[VN], xh[VN];
         dyhat(p, d, xh);
 #pragma unroll
@@ -469,7 +528,7 @@ static inline int pick_cb(int C) { return C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 1
 extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const void* raw, int raw_kind, int nslabs,
                                 long long slab_stride, const float* gamma, const float* beta, float eps, int act,
                                 float alpha, const unsigned char* mask, const p2p_tensor* out, void* raw_out,
-                                float* stats, void* stream) {
+                                float* stats, float* ws, long long ws_bytes, int nsplit, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_norm_act_fwd: bad shape");
     P2P_REQUIRE(raw && out && out->ptr, "p2p_norm_act_fwd: null pointer");
     P2P_REQUIRE(raw_kind == 1 || (raw_kind == 2 && nslabs >= 1), "p2p_norm_act_fwd: bad raw_kind/nslabs");
@@ -483,10 +542,24 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
         while (C % CG) CG -= vn;
         int vpp = CG / vn;
         if (256 % vpp == 0) {
-            dim3 grid(N, C / CG);
-            P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T><<<grid, 256, 0, (hipStream_t)stream>>>(
-                                          H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                          make_view(out), (T*)raw_out, stats)));
+            hipStream_t st = (hipStream_t)stream;
+            const int prr = 256 / vpp;
+            int sp = nsplit < 1 ? 1 : nsplit;
+            while (sp > 1 && (H * W + sp - 1) / sp < prr) sp >>= 1;       // every split keeps all pixel lanes busy
+            if (!ws || (long long)N * sp * C * 2 * 4 > ws_bytes) sp = gamma ? 1 : sp;
+            dim3 grid(N, C / CG, sp);
+            if (sp == 1 || !gamma) {
+                P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 0><<<grid, 256, 0, st>>>(
+                                              H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
+                                              make_view(out), (T*)raw_out, stats, ws)));
+            } else {
+                P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 1><<<grid, 256, 0, st>>>(
+                                              H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
+                                              make_view(out), (T*)raw_out, stats, ws)));
+                P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 2><<<grid, 256, 0, st>>>(
+                                              H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
+                                              make_view(out), (T*)raw_out, stats, ws)));
+            }
             return p2p_check_launch("p2p_norm_act_fwd");
         }
     }
@@ -502,7 +575,8 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
 extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const void* raw, const float* stats,
                                 const float* gamma, const float* beta, int act, float alpha,
                                 const unsigned char* mask, const p2p_gsrc* g1, const p2p_gsrc* g2,
-                                const p2p_tensor* draw, float* dgamma_part, float* dbeta_part, void* stream) {
+                                const p2p_tensor* draw, float* dgamma_part, float* dbeta_part, float* ws,
+                                long long ws_bytes, int nsplit, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_norm_act_bwd: bad shape");
     P2P_REQUIRE(raw && draw && draw->ptr && g1, "p2p_norm_act_bwd: null pointer");
     P2P_REQUIRE(!gamma || (stats && beta && dgamma_part && dbeta_part), "p2p_norm_act_bwd: norm needs stats/beta/partials");
@@ -519,10 +593,24 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
         while (C % CG) CG -= vn;
         int vpp = CG / vn;
         if (256 % vpp == 0) {
-            dim3 grid(N, C / CG);
-            P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T><<<grid, 256, 0, (hipStream_t)stream>>>(
-                                          H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
-                                          make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)));
+            hipStream_t st = (hipStream_t)stream;
+            const int prr = 256 / vpp;
+            int sp = nsplit < 1 ? 1 : nsplit;
+            while (sp > 1 && (H * W + sp - 1) / sp < prr) sp >>= 1;
+            if (!ws || (long long)N * sp * C * 2 * 4 > ws_bytes) sp = 1;
+            dim3 grid(N, C / CG, sp);
+            if (sp == 1) {
+                P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T, 0><<<grid, 256, 0, st>>>(
+                                              H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
+                                              make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws)));
+            } else {
+                P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T, 1><<<grid, 256, 0, st>>>(
+                                              H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
+                                              make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws)));
+                P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T, 2><<<grid, 256, 0, st>>>(
+                                              H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
+                                              make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws)));
+            }
             return p2p_check_launch("p2p_norm_act_bwd");
         }
     }

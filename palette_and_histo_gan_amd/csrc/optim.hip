@@ -31,6 +31,66 @@ extern "C" int p2p_adam_flat(float* p, const float* g, float* m, float* v, long 
     return p2p_check_launch("p2p_adam_flat");
 }
 
+// Device-resident step state, so that a whole train step can be captured once in a hipGraph and replayed: the Adam
+// iteration count / bias-corrected step size and the dropout counter live in HBM and are advanced by these kernels.
+__global__ void adam_tick_kernel(int* __restrict__ t, float* __restrict__ lr_t, float lr, float b1, float b2) {
+    int tt = t[0] + 1;
+    t[0] = tt;
+    lr_t[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)tt)) / (1.0 - pow((double)b1, (double)tt)));
+}
+
+__global__ void adam_flat_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                     float* __restrict__ v, long long n, const float* __restrict__ lr_t_dev, float b1,
+                                     float b2, float eps, float gscale) {
+    const float lr_t = lr_t_dev[0];
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        f32x4 gi = *(const f32x4*)(g + i), mi = *(const f32x4*)(m + i), vi = *(const f32x4*)(v + i), pi = *(const f32x4*)(p + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gg = gi[k] * gscale;
+            mi[k] = b1 * mi[k] + (1.f - b1) * gg;
+            vi[k] = b2 * vi[k] + (1.f - b2) * gg * gg;
+            pi[k] = pi[k] - lr_t * mi[k] / (sqrtf(vi[k]) + eps);
+        }
+        *(f32x4*)(m + i) = mi; *(f32x4*)(v + i) = vi; *(f32x4*)(p + i) = pi;
+    }
+    // tail (n is padded to a multiple of 4 by the host layout, kept for safety)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long long j = n / 4 * 4; j < n; ++j) {
+            float gg = g[j] * gscale;
+            float mj = b1 * m[j] + (1.f - b1) * gg, vj = b2 * v[j] + (1.f - b2) * gg * gg;
+            m[j] = mj; v[j] = vj; p[j] = p[j] - lr_t * mj / (sqrtf(vj) + eps);
+        }
+}
+
+extern "C" int p2p_adam_tick(int* t_dev, float* lr_t_dev, float lr, float beta1, float beta2, void* stream) {
+    P2P_REQUIRE(t_dev && lr_t_dev, "p2p_adam_tick: null pointer");
+    adam_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>(t_dev, lr_t_dev, lr, beta1, beta2);
+    return p2p_check_launch("p2p_adam_tick");
+}
+
+extern "C" int p2p_adam_flat_dev(float* p, const float* g, float* m, float* v, long long n, const float* lr_t_dev,
+                                 float beta1, float beta2, float eps, float gscale, void* stream) {
+    P2P_REQUIRE(p && g && m && v && n > 0 && lr_t_dev, "p2p_adam_flat_dev: bad args");
+    P2P_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+                "p2p_adam_flat_dev: buffers must be 16-byte aligned");
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    adam_flat_dev_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr_t_dev, beta1, beta2, eps, gscale);
+    return p2p_check_launch("p2p_adam_flat_dev");
+}
+
+__global__ void counter_add_kernel(long long* c, long long inc) { c[0] += inc; }
+
+extern "C" int p2p_counter_add(long long* counter_dev, long long inc, void* stream) {
+    P2P_REQUIRE(counter_dev, "p2p_counter_add: null pointer");
+    counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter_dev, inc);
+    return p2p_check_launch("p2p_counter_add");
+}
+
 // wn[t][g][d] = T(w[t][g][d]) for g < wn_rows, d < wn_cols;  wt[t][d][g] = T(w[t][g][d]) for d < wt_rows,
 // g < wt_cols; entries outside the real [Cg][Cd] block are written as zeros (channel padding of the edge
 // layers).  32x32 LDS tile transpose per tap.
@@ -123,7 +183,8 @@ extern "C" int p2p_unpack(int dtype, int N, int H, int W, int C, const p2p_tenso
 // Bernoulli(0.5) keep mask of keras Dropout(0.5) (networks.py:31-32): counter-based (splitmix64 of
 // seed, call counter, element index), one byte per element, 8 elements per hash.
 __global__ void dropout_mask_kernel(unsigned char* __restrict__ mask, long long n, unsigned long long seed,
-                                    unsigned long long counter) {
+                                    unsigned long long counter, const long long* __restrict__ counter_dev) {
+    if (counter_dev) counter += (unsigned long long)counter_dev[0] * 16ull;      // device step counter (graph replay)
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (; i * 8 < n; i += stride) {
@@ -142,6 +203,18 @@ extern "C" int p2p_dropout_mask(unsigned char* mask, long long n, long long seed
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     dropout_mask_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(mask, n, (unsigned long long)seed,
-                                                                                (unsigned long long)counter);
+                                                                                (unsigned long long)counter, nullptr);
     return p2p_check_launch("p2p_dropout_mask");
+}
+
+// same, with the call counter = counter_dev[0] * 16 + salt read on the device (one salt per dropout layer)
+extern "C" int p2p_dropout_mask_dev(unsigned char* mask, long long n, long long seed, const long long* counter_dev,
+                                    long long salt, void* stream) {
+    P2P_REQUIRE(mask && n > 0 && counter_dev, "p2p_dropout_mask_dev: bad args");
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    dropout_mask_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(mask, n, (unsigned long long)seed,
+                                                                                (unsigned long long)salt, counter_dev);
+    return p2p_check_launch("p2p_dropout_mask_dev");
 }

@@ -32,6 +32,35 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _SideStream:
+    """Fork/join helper: weight-gradient GEMMs only feed Adam, so they run on a second HIP stream concurrently with
+    the data-gradient chain (the critical path of the backward pass).  fork() makes the side stream wait for
+    everything issued so far on the main stream; join() makes the main stream wait for the side stream."""
+
+    def __init__(self, device, enabled):
+        self.enabled = enabled and torch.device(device).type == "cuda"
+        self.stream = torch.cuda.Stream(device=device) if self.enabled else None
+
+    def fork(self):
+        if self.enabled:
+            self.stream.wait_stream(torch.cuda.current_stream())
+
+    def run(self):
+        return torch.cuda.stream(self.stream) if self.enabled else _NullCtx()
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class HaloBuf:
     """NHWC activation buffer with a zero halo of HALO pixels around every image."""
 
@@ -98,7 +127,9 @@ class ParamStore:
         self.grads = torch.zeros(off, dtype=torch.float32, device=device)
         self.m = torch.zeros(off, dtype=torch.float32, device=device)
         self.v = torch.zeros(off, dtype=torch.float32, device=device)
-        self.t = 0                            # Adam iteration count
+        self.t = 0                            # Adam iteration count (host mirror of t_dev)
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=device)       # device-resident: graph replay advances it
+        self.lr_t_dev = torch.zeros(1, dtype=torch.float32, device=device)
 
     def count(self):
         return int(sum(int(np.prod(s)) for s in self.shapes.values()))
@@ -169,7 +200,7 @@ class Pix2PixEngine:
     """One generator + one discriminator + their optimizers on one GPU."""
 
     def __init__(self, in_ch=4, out_ch=4, head="tanh", img_size=64, dtype=L.BF16, device="cuda:0", seed=47,
-                 use_mfma=True):
+                 use_mfma=True, overlap_wgrad=True):
         assert img_size % 64 == 0 and (img_size & (img_size - 1)) == 0, "IMG_SIZE must be a power of two >= 64"
         L.lib()       # fail loudly now if the HIP library is missing
         self.in_ch, self.out_ch, self.head, self.S = in_ch, out_ch, head, img_size
@@ -178,7 +209,8 @@ class Pix2PixEngine:
         self.G = ParamStore(generator_param_shapes(in_ch, out_ch), self.device)
         self.D = ParamStore(discriminator_param_shapes(in_ch), self.device)
         self.rng = np.random.default_rng(seed)
-        self.seed, self.mask_counter = int(seed), 0
+        self.seed = int(seed)
+        self.mask_counter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)    # advanced once per step on the device
         self._init_params()
         self.c6_ch = pad8(UP_FILTERS[5] + in_ch)          # [up6 32 | source | zero pad]
         self.src_ch = pad8(in_ch)
@@ -190,6 +222,7 @@ class Pix2PixEngine:
         self.lr, self.beta1, self.beta2, self.adam_eps = 2e-4, 0.5, 0.999, 1e-7   # pix2pix_model.py:28-29
         self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
         self.step_count = 0
+        self.side = _SideStream(self.device, overlap_wgrad)
         self.refresh_weight_copies()
 
     # ------------------------------------------------------------------ parameters
@@ -320,9 +353,12 @@ class Pix2PixEngine:
         P["dlg"] = HaloBuf(B, h2, h2, 8, dt, dev)
         P["g_dact"] = DenseBuf(2 * B, h2, h2, 64, tdt, dev)
         P["d_draw"] = HaloBuf(2 * B, h2, h2, 64, dt, dev)
+        P["d_draw_g"] = HaloBuf(B, h2, h2, 64, dt, dev)      # generator path: own buffer (D.down's wgrad may still read d_draw)
+        P["g_dact_g"] = DenseBuf(B, h2, h2, 64, tdt, dev)
         P["g_dcat"] = DenseBuf(B, S, S, self.dcat_ch, tdt, dev)
         if not self.use_mfma:
             P["d_raw"] = DenseBuf(2 * B, h2, h2, 64, tdt, dev)
+        P["nws"] = torch.empty(max(B, 2) * 16 * 1024 * 2, dtype=torch.float32, device=dev)   # norm split partials [N][16][C<=1024][2]
         # split-K / wgrad workspaces
         P["slabs"] = torch.empty(self._max_slab_elems(B), dtype=torch.float32, device=dev)
         P["wws"] = torch.empty(self._max_wgrad_ws(B) // 4 + 4, dtype=torch.float32, device=dev)
@@ -415,13 +451,20 @@ class Pix2PixEngine:
             L.call("p2p_conv_direct", op, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(tmp.view()),
                    self._wd(sid, name), bias if bias is not None else NULL, NULL, NULL, _stream())
             L.call("p2p_norm_act_fwd", self.dtype, N, lh, lh, cd, tmp.ptr(), 1, 1, 0, NULL, NULL, IN_EPS, act,
-                   LEAKY_ALPHA, NULL, C.byref(out_view), NULL, NULL, _stream())
+                   LEAKY_ALPHA, NULL, C.byref(out_view), NULL, NULL, NULL, 0, 1, _stream())
         else:
             L.call("p2p_conv_direct", op, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo),
                    self._wd(sid, name), bias if bias is not None else NULL, NULL, NULL, _stream())
         return (1, 1)
 
     def _wgrad(self, P, sid, name, N, lh, hi, lo, stride=2, dbias=None):
+        """dW (and dbias) of one layer, issued on the side stream: its inputs were produced on the main stream
+        before this call (fork), its outputs are only read by Adam (join in _finish_step)."""
+        self.side.fork()
+        with self.side.run():
+            self._wgrad_impl(P, sid, name, N, lh, hi, lo, stride, dbias)
+
+    def _wgrad_impl(self, P, sid, name, N, lh, hi, lo, stride=2, dbias=None):
         lw = self.W[(sid, name)]
         cg, cd = lw.cg, lw.cd
         dw = self._store(sid).g(name + ".kernel")
@@ -438,6 +481,18 @@ class Pix2PixEngine:
         if dbias is not None:
             L.call("p2p_view_colsum", self.dtype, N, lh, lh, cd, C.byref(lo), dbias, _stream())
 
+    def _nsplit(self, N, res, c, bwd=False):
+        """Pixel-range splits of the InstanceNorm kernels.  Measured on MI355X (B=256): the split form re-reads the
+        image from HBM in its second launch, where the one-launch form re-reads it from L2, so it only pays for the
+        backward kernel (three input streams) when there would be fewer than ~512 workgroups."""
+        if not bwd:
+            return 1
+        groups = max(1, c // 64)
+        sp = 1
+        while N * groups * sp < 512 and res * res // (sp * 2) >= 64 and sp < 16:
+            sp *= 2
+        return sp
+
     def _norm_fwd(self, P, N, res, c, raw_buf, rk, gamma, beta, act, mask, out_view, stats):
         raw_kind, nslabs = rk
         raw = raw_buf.ptr() if raw_kind == 1 else _p(P["slabs"])
@@ -445,7 +500,8 @@ class Pix2PixEngine:
         L.call("p2p_norm_act_fwd", self.dtype, N, res, res, c, raw, raw_kind, nslabs, slab,
                gamma if gamma is not None else NULL, beta if beta is not None else NULL, IN_EPS, act, LEAKY_ALPHA,
                _p(mask) if mask is not None else NULL, C.byref(out_view),
-               raw_buf.ptr() if raw_kind == 2 else NULL, _p(stats) if stats is not None else NULL, _stream())
+               raw_buf.ptr() if raw_kind == 2 else NULL, _p(stats) if stats is not None else NULL,
+               _p(P["nws"]), P["nws"].numel() * 4, self._nsplit(N, res, c), _stream())
 
     def _gs(self, P, buf, rk, coff=0):
         """gradient source for a conv result that went to `buf` (kind 1) or to the split-K slabs (kind 2)."""
@@ -457,7 +513,8 @@ class Pix2PixEngine:
         ob, og = P["part_off"][name]
         L.call("p2p_norm_act_bwd", self.dtype, N, res, res, c, raw_buf.ptr(), _p(stats), self.G.p(name + ".gamma"),
                self.G.p(name + ".beta"), act, LEAKY_ALPHA, _p(mask) if mask is not None else NULL, C.byref(g1),
-               C.byref(g2) if g2 is not None else None, C.byref(draw_view), _p(P["part"], og), _p(P["part"], ob), _stream())
+               C.byref(g2) if g2 is not None else None, C.byref(draw_view), _p(P["part"], og), _p(P["part"], ob),
+               _p(P["nws"]), P["nws"].numel() * 4, self._nsplit(N, res, c, bwd=True), _stream())
 
     def _act_bwd(self, N, res, c, act_view, g1, g2, draw_view):
         L.call("p2p_act_bwd", self.dtype, N, res, res, c, C.byref(act_view), C.byref(g1),
@@ -510,8 +567,7 @@ class Pix2PixEngine:
                 if masks is not None:
                     mask.copy_(torch.as_tensor(masks[i - 1]).reshape(mask.shape).to(torch.uint8))
                 else:       # Bernoulli(0.5) keep mask (networks.py:31-32), counter-based device RNG
-                    self.mask_counter += 1
-                    L.call("p2p_dropout_mask", _p(mask), mask.numel(), self.seed, self.mask_counter, _stream())
+                    L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self.seed, _p(self.mask_counter_dev), i, _stream())
             self._norm_fwd(P, B, 2 * lh, f, P["ru"][i], rk, self.G.p(f"up{i}.gamma"), self.G.p(f"up{i}.beta"),
                            L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i])
             lo_view = c[i].view()
@@ -534,9 +590,9 @@ class Pix2PixEngine:
         self._wgrad(P, "D", "down", 2 * B, h2, P["dcat"].view(), P["d_draw"].view())
         if P.get("skip_g_through_d"):
             return
-        self._conv(P, L.OP_P, "D", "last", B, h2, P["dlg"].view(), P["g_dact"].view(), stride=1)
-        self._act_bwd(B, h2, 64, P["d_act"].view(n0=B), P["g_dact"].gsrc(), None, P["d_draw"].view())
-        self._conv(P, L.OP_P, "D", "down", B, h2, P["d_draw"].view(), P["g_dcat"].view(), ncols=ic)
+        self._conv(P, L.OP_P, "D", "last", B, h2, P["dlg"].view(), P["g_dact_g"].view(), stride=1)
+        self._act_bwd(B, h2, 64, P["d_act"].view(n0=B), P["g_dact_g"].gsrc(), None, P["d_draw_g"].view())
+        self._conv(P, L.OP_P, "D", "down", B, h2, P["d_draw_g"].view(), P["g_dcat"].view(), ncols=ic)
 
     # ------------------------------------------------------------------ train step (RGBA models)
     def train_step_rgba(self, source, real, lambda_l1, lambda_hist=None, masks=None, global_batch=None,
@@ -628,10 +684,11 @@ class Pix2PixEngine:
             return rk
         L.call("p2p_norm_act_fwd", self.dtype, buf.n, buf.h, buf.w, buf.c, _p(P["slabs"]), 2, rk[1],
                buf.n * buf.h * buf.w * buf.c, NULL, NULL, IN_EPS, L.ACT_NONE, 0.0, NULL, C.byref(buf.view()),
-               NULL, NULL, _stream())
+               NULL, NULL, NULL, 0, self._nsplit(buf.n, buf.h, buf.c), _stream())
         return (1, 1)
 
     def _finish_step(self, P, lambda_l1, lambda_hist, apply_update, allreduce):
+        self.side.join()
         if allreduce is not None:
             allreduce(self.G.grads, self.D.grads, self.losses)
         if apply_update:
@@ -648,8 +705,10 @@ class Pix2PixEngine:
         """Both optimizers step with gradients taken at the same pre-update weights (pix2pix_model.py:81-83)."""
         for store in (self.G, self.D):
             store.t += 1
-            L.call("p2p_adam_flat", _p(store.params), _p(store.grads), _p(store.m), _p(store.v), store.numel,
-                   store.t, self.lr, self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+            L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
+            L.call("p2p_adam_flat_dev", _p(store.params), _p(store.grads), _p(store.m), _p(store.v), store.numel,
+                   _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+        L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
         self.refresh_weight_copies()
 
     def _histogram_loss(self, P, B, Bg, lambda_hist, hist_allreduce):
@@ -726,6 +785,7 @@ class Pix2PixEngine:
         P["skip_g_through_d"] = True
         self.discriminator_backward(P, B)
         self.generator_backward(P)
+        self.side.join()
         if allreduce is not None:
             allreduce(self.G.grads, self.D.grads, self.losses)
         if apply_update:
@@ -767,6 +827,46 @@ class Pix2PixEngine:
         L.call("p2p_argmax_lastdim", _p(probs), B * S * S, self.out_ch, _p(idx), _stream())
         idx = idx.view(B, S, S, 1)
         return (idx, probs) if with_probs else idx
+
+    # ------------------------------------------------------------------ hipGraph replay of the whole step
+    def graphed_rgba_step(self, B, lambda_l1, lambda_hist=None, global_batch=None):
+        """Captures one whole train step (about 130 kernel launches on two streams) into a hipGraph and returns
+        step(source, real) -> losses that copies the batch into static buffers and replays it.  Everything that
+        changes from step to step (Adam's t / step size, the dropout counter) lives in device memory.  Single-GPU
+        only: the gradient all-reduce stays outside graphs."""
+        S, ic = self.S, self.in_ch
+        src_s = torch.zeros((B, S, S, ic), dtype=torch.float32, device=self.device)
+        real_s = torch.zeros((B, S, S, ic), dtype=torch.float32, device=self.device)
+        # warm-up on a snapshot: allocates every buffer of the plan, loads every code object, then rolls the state back
+        snap = [(t, t.clone()) for st in (self.G, self.D) for t in (st.params, st.m, st.v, st.t_dev, st.lr_t_dev)]
+        snap.append((self.mask_counter_dev, self.mask_counter_dev.clone()))
+        t_host = (self.G.t, self.D.t)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.train_step_rgba(src_s, real_s, lambda_l1, lambda_hist, global_batch=global_batch)
+        torch.cuda.current_stream().wait_stream(side)
+        for t, c in snap:
+            t.copy_(c)
+        self.G.t, self.D.t = t_host
+        self.refresh_weight_copies()
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.train_step_rgba(src_s, real_s, lambda_l1, lambda_hist, global_batch=global_batch)
+        self.G.t, self.D.t = t_host       # the capture pass only recorded; host mirrors advance per replay below
+
+        def step(source, real):
+            src_s.copy_(torch.as_tensor(source), non_blocking=True)
+            real_s.copy_(torch.as_tensor(real), non_blocking=True)
+            graph.replay()
+            self.G.t += 1
+            self.D.t += 1
+            self.step_count += 1
+            return out
+
+        step.graph = graph
+        return step
 
     # ------------------------------------------------------------------ inference-style helpers
     def generate(self, source, masks=None):

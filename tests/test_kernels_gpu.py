@@ -112,11 +112,13 @@ def test_wgemm(dtype, n, lh, cg, cd, msplit):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n,h,c,act,use_mask,norm", [(2, 4, 64, L.ACT_LEAKY, False, True), (3, 8, 32, L.ACT_RELU, True, True),
-                                                      (2, 1, 512, L.ACT_LEAKY, False, True), (2, 4, 36, L.ACT_RELU, True, True),
-                                                      (2, 8, 64, L.ACT_LEAKY, False, False)])
-def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm):
+@pytest.mark.parametrize("n,h,c,act,use_mask,norm,nsplit", [
+    (2, 4, 64, L.ACT_LEAKY, False, True, 1), (3, 8, 32, L.ACT_RELU, True, True, 1), (2, 1, 512, L.ACT_LEAKY, False, True, 4),
+    (2, 4, 36, L.ACT_RELU, True, True, 1), (2, 8, 64, L.ACT_LEAKY, False, False, 2), (2, 32, 32, L.ACT_RELU, False, True, 4),
+    (3, 16, 128, L.ACT_LEAKY, True, True, 8)])
+def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm, nsplit):
     rng = np.random.default_rng(13)
+    nws = torch.empty(n * 16 * c * 2, dtype=torch.float32, device=U.DEV)
     x = U.q(rng.normal(size=(n, h, h, c)) * 2 + 0.3, dtype)
     gamma = (1 + 0.2 * rng.normal(size=c)).astype(np.float32)
     beta = (0.2 * rng.normal(size=c)).astype(np.float32)
@@ -141,7 +143,7 @@ def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm):
     mask_d = U.dev(mask.reshape(-1, c), torch.uint8) if use_mask else None
     L.call("p2p_norm_act_fwd", dtype, n, h, h, c, raw.ptr(), 1, 1, 0, U.ptr(g_d) if norm else None,
            U.ptr(b_d) if norm else None, 1e-3, act, 0.3, U.ptr(mask_d) if use_mask else None, C.byref(out.view(coff=4)),
-           None, U.ptr(stats) if norm else None, U.stream())
+           None, U.ptr(stats) if norm else None, U.ptr(nws), nws.numel() * 4, nsplit, U.stream())
     got = U.halo_to_np(out)
     assert np.count_nonzero(got[..., :4]) == 0
     assert U.rel_err(got[..., 4:], y.detach().numpy()) < OUT_TOL[dtype]
@@ -156,7 +158,7 @@ def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm):
     L.call("p2p_norm_act_bwd", dtype, n, h, h, c, raw.ptr(), U.ptr(stats) if norm else None,
            U.ptr(g_d) if norm else None, U.ptr(b_d) if norm else None, act, 0.3, U.ptr(mask_d) if use_mask else None,
            C.byref(g1.gsrc(coff=8)), C.byref(gs2), C.byref(draw.view()), U.ptr(part[1]) if norm else None,
-           U.ptr(part[0]) if norm else None, U.stream())
+           U.ptr(part[0]) if norm else None, U.ptr(nws), nws.numel() * 4, nsplit, U.stream())
     ref_dx = xt.grad.numpy()
     scale = np.abs(ref_dx).max() + 1e-30
     assert np.abs(U.halo_to_np(draw) - ref_dx).max() / scale < (1e-4 if dtype == L.F32 else 1e-2)
