@@ -118,7 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-mfma", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a hipGraph (N=1 only uses graphs)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one captured hipGraph (N=1 only). Measured "
+                    "slower than eager two-stream launching on ROCm 7.2 (the replay serialises the weight-gradient branch), so off by default")
     ap.add_argument("--detail", default=None, help="write a per-call (entry point, shape) device-time table to this file")
     args = ap.parse_args()
 
@@ -147,7 +148,7 @@ def main():
         return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, allreduce=allreduce,
                                    hist_allreduce=hist_allreduce)
 
-    use_graph = world == 1 and not args.no_graph
+    use_graph = world == 1 and args.graph
     if use_graph:
         graphed = eng.graphed_rgba_step(B, lam_l1, lam_hist, global_batch=B)
 

@@ -224,6 +224,14 @@ int p2p_weight_prep_pad(int dtype, const float* w, int Cg, int Cd, void* wn, int
 /* dense f32 (or i32 if src_is_int) [N][H][W][C] host-layout batch -> view in `dtype` (dataset_utils.py:39-48 contract). */
 int p2p_pack_input(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
                    const p2p_tensor* dst, void* stream);
+/* same batch into ndst (1..4) views with one read (dsts = array of p2p_tensor). */
+int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
+                         const p2p_tensor* dsts, int ndst, void* stream);
+/* out[7] = [g_total, g_adv, g_l1, g_aux, d_total, d_real, d_fake] from the loss slots written by the loss kernels:
+ * slots[0..2] = BCE(1,real), BCE(0,fake), BCE(1,fake); slots[l1_slot] = L1; slots[aux_slot] = histogram /
+ * segmentation loss (aux_slot < 0: none); g_total = adv + lambda_l1*l1 + lambda_aux*aux. */
+int p2p_finish_losses(const float* slots, int aux_slot, int l1_slot, float lambda_l1, float lambda_aux, float* out,
+                      void* stream);
 /* view in `dtype` -> dense f32 [N][H][W][C] (for generate()/tests). */
 int p2p_unpack(int dtype, int N, int H, int W, int C, const p2p_tensor* src, float* dst, void* stream);
 

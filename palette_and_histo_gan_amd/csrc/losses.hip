@@ -108,7 +108,9 @@ extern "C" int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(l1_out, 0, sizeof(float), st);
     if (e != hipSuccess) { p2p_set_error("p2p_tanh_l1_fwd memset: %s", hipGetErrorString(e)); return (int)e; }
-    P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_kernel<T><<<dim3(grid_for((long long)N * H * W * C)), 256, 0, st>>>(
+    long long tb = ((long long)N * H * W * C + 1023) / 1024;      // 4 elements per thread, one atomic per workgroup
+    if (tb > 1024) tb = 1024;
+    P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_kernel<T><<<dim3((unsigned)(tb < 1 ? 1 : tb)), 256, 0, st>>>(
                                   N, H, W, C, make_view(z), make_view(real), make_view(fake), inv_count, l1_out)));
     return p2p_check_launch("p2p_tanh_l1_fwd");
 }

@@ -147,6 +147,57 @@ __global__ void pack_input_kernel(int N, int H, int W, int C, const void* __rest
     }
 }
 
+// One launch scatters a dense batch into up to 4 views (the source image feeds down1, the last skip connection and
+// both discriminator inputs; networks.py:45,92-94): read once, write everywhere.
+struct PackDst { TView v[4]; int n; };
+
+template <typename T>
+__global__ void pack_multi_kernel(int N, int H, int W, int C, const void* __restrict__ src, int src_is_int, PackDst dst) {
+    long long total = (long long)N * H * W;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+        int x = (int)(p % W);
+        int y = (int)((p / W) % H);
+        int n = (int)(p / ((long long)W * H));
+        for (int c = 0; c < C; ++c) {
+            float v = src_is_int ? (float)((const int*)src)[p * C + c] : ((const float*)src)[p * C + c];
+            T q = from_f32<T>(v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < dst.n) ((T*)dst.v[k].ptr)[dst.v[k].off(n, y, x) + c] = q;
+        }
+    }
+}
+
+extern "C" int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
+                                    const p2p_tensor* dsts, int ndst, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && src && dsts && ndst >= 1 && ndst <= 4, "p2p_pack_input_multi: bad args");
+    PackDst d;
+    d.n = ndst;
+    for (int k = 0; k < 4; ++k) d.v[k] = make_view(&dsts[k < ndst ? k : 0]);
+    long long total = (long long)N * H * W;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    P2P_DISPATCH_DTYPE(dtype, (pack_multi_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(N, H, W, C, src, src_is_int, d)));
+    return p2p_check_launch("p2p_pack_input_multi");
+}
+
+// out[0..6] = [g_total, g_adv, g_l1, g_aux, d_total, d_real, d_fake] from the loss slots (pix2pix_model.py:44-56,
+// 242-250,273-278): g_total = adv + lambda_l1 * l1 + lambda_aux * aux, d_total = real + fake.
+__global__ void finish_losses_kernel(const float* __restrict__ l, int aux_slot, int l1_slot, float lambda_l1, float lambda_aux,
+                                     float* __restrict__ out) {
+    float adv = l[2], l1 = l[l1_slot], aux = aux_slot >= 0 ? l[aux_slot] : 0.f;
+    out[0] = adv + lambda_l1 * l1 + lambda_aux * aux;
+    out[1] = adv; out[2] = l1; out[3] = aux;
+    out[4] = l[0] + l[1]; out[5] = l[0]; out[6] = l[1];
+}
+
+extern "C" int p2p_finish_losses(const float* slots, int aux_slot, int l1_slot, float lambda_l1, float lambda_aux, float* out,
+                                 void* stream) {
+    P2P_REQUIRE(slots && out && l1_slot >= 0, "p2p_finish_losses: bad args");
+    finish_losses_kernel<<<1, 1, 0, (hipStream_t)stream>>>(slots, aux_slot, l1_slot, lambda_l1, lambda_aux, out);
+    return p2p_check_launch("p2p_finish_losses");
+}
+
 template <typename T>
 __global__ void unpack_kernel(int N, int H, int W, int C, TView src, float* __restrict__ dst) {
     long long total = (long long)N * H * W * C;

@@ -534,10 +534,19 @@ class Pix2PixEngine:
         is_int = t.dtype == torch.int32
         L.call("p2p_pack_input", self.dtype, P["B"], self.S, self.S, c, _p(t), 1 if is_int else 0, C.byref(view), _stream())
 
-    def _pack_source(self, P, src_t):
-        ic = self.in_ch
-        self._pack(P, src_t, P["src"].view(), ic)                               # down1 input
-        self._pack(P, src_t, P["c"][6].view(coff=UP_FILTERS[5]), ic)            # last skip = raw input (networks.py:92)
+    def _pack_multi(self, P, t, views, c):
+        arr = (L.Tensor * len(views))(*views)
+        L.call("p2p_pack_input_multi", self.dtype, P["B"], self.S, self.S, c, _p(t), 1 if t.dtype == torch.int32 else 0,
+               arr, len(views), _stream())
+
+    def _pack_source(self, P, src_t, with_disc=False):
+        """the source image feeds down1, the last skip connection (networks.py:92) and, in a train step, the second half
+        of both discriminator inputs (networks.py:45): one read, up to four writes"""
+        ic, B = self.in_ch, P["B"]
+        views = [P["src"].view(), P["c"][6].view(coff=UP_FILTERS[5])]
+        if with_disc:
+            views += [P["dcat"].view(coff=ic), P["dcat"].view(coff=ic, n0=B)]
+        self._pack_multi(P, src_t, views, ic)
 
     def generator_forward(self, P, masks=None):
         """UnetGenerator forward up to the pre-activation head output z (networks.py:80-98)."""
@@ -604,9 +613,7 @@ class Pix2PixEngine:
         S, ic = self.S, self.in_ch
         Bg = global_batch or B
         src_t, real_t = self._to_device(source, ic, B), self._to_device(real, ic, B)
-        self._pack_source(P, src_t)
-        self._pack(P, src_t, P["dcat"].view(coff=ic), ic)
-        self._pack(P, src_t, P["dcat"].view(coff=ic, n0=B), ic)
+        self._pack_source(P, src_t, with_disc=True)
         self._pack(P, real_t, P["dcat"].view(coff=0), ic)
         self.generator_forward(P, masks)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
@@ -693,13 +700,11 @@ class Pix2PixEngine:
             allreduce(self.G.grads, self.D.grads, self.losses)
         if apply_update:
             self.apply_adam()
-        l = self.losses
-        hist = l[4] if lambda_hist is not None else torch.zeros((), device=self.device)
-        g_adv, g_l1 = l[2], l[3]
-        g_total = g_adv + float(lambda_l1) * g_l1 + (float(lambda_hist) * hist if lambda_hist is not None else 0.0)
-        d_real, d_fake = l[0], l[1]
+        out = torch.empty(8, dtype=torch.float32, device=self.device)
+        L.call("p2p_finish_losses", _p(self.losses), 4 if lambda_hist is not None else -1, 3, float(lambda_l1),
+               float(lambda_hist) if lambda_hist is not None else 0.0, _p(out), _stream())
         self.step_count += 1
-        return torch.stack([g_total, g_adv, g_l1, hist, d_real + d_fake, d_real, d_fake])
+        return out[:7]
 
     def apply_adam(self):
         """Both optimizers step with gradients taken at the same pre-update weights (pix2pix_model.py:81-83)."""
@@ -768,9 +773,7 @@ class Pix2PixEngine:
         Bg = global_batch or B
         src_t = self._to_device(source_idx, 1, B, is_int=True)
         real_t = self._to_device(real_idx, 1, B, is_int=True)
-        self._pack_source(P, src_t)
-        self._pack(P, src_t, P["dcat"].view(coff=1), 1)
-        self._pack(P, src_t, P["dcat"].view(coff=1, n0=B), 1)
+        self._pack_source(P, src_t, with_disc=True)
         self._pack(P, real_t, P["dcat"].view(coff=0), 1)
         self.generator_forward(P, masks)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
@@ -790,11 +793,11 @@ class Pix2PixEngine:
             allreduce(self.G.grads, self.D.grads, self.losses)
         if apply_update:
             self.apply_adam()
-        l = self.losses
-        g_adv, seg, l1 = l[2], l[5], l[6]
-        g_total = g_adv + 0.0 * l1 + float(lambda_segmentation) * seg
+        out = torch.empty(8, dtype=torch.float32, device=self.device)
+        # g_total = adv + 0 * l1 + lambda_seg * seg  (lambda_l1 is hard-wired to 0, pix2pix_model.py:263,273-278)
+        L.call("p2p_finish_losses", _p(self.losses), 5, 6, 0.0, float(lambda_segmentation), _p(out), _stream())
         self.step_count += 1
-        return torch.stack([g_total, g_adv, l1, seg, l[0] + l[1], l[0], l[1]])
+        return out[:7]
 
     def discriminate(self, target, source):
         """discriminator([target, source], training=True) (pix2pix_model.py:69-70): f32 device logits (B,S/2,S/2,1)."""
