@@ -46,7 +46,9 @@ def cpu_baseline(model, S, lambda_l1, lambda_hist, budget_s=20.0):
     """The oracle (torch-CPU f32 restatement of the reference graph, TF 2.9.1 is not installable here) timed
     on the host cores, on a bounded sample: B=4 batches (the reference's own batch size, configuration.py:24)."""
     from oracle import reference_graph as rg
-    cores = os.cpu_count() or 1
+    # the box's CPU share for one GPU is 16 cores; more threads than that only adds contention in the small
+    # (B=4) convolutions (256 threads: 70 s per step, measured)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(47)
     Gp = rg.init_params(rg.generator_param_shapes(4, 4), rng, torch.float32)
