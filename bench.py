@@ -142,13 +142,9 @@ def main():
     src, tgt = synthetic_batch(rank, B, S, palette)
     src_d = torch.as_tensor(src).to(device)
     tgt_d = torch.as_tensor(tgt).to(device)
-    allreduce = comm.allreduce_grads if comm is not None else None
-
-    hist_allreduce = comm.allreduce_scalar_sum if comm is not None else None
 
     def run_step_eager():
-        return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, allreduce=allreduce,
-                                   hist_allreduce=hist_allreduce)
+        return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, dp=comm)
 
     use_graph = world == 1 and args.graph
     if use_graph:

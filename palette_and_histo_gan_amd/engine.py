@@ -112,16 +112,41 @@ NULL = C.c_void_p(0)
 
 
 class ParamStore:
-    """Flat f32 parameter / gradient / Adam-moment buffers with named views (Keras variable order)."""
+    """Flat f32 parameter / gradient / Adam-moment buffers with named views.
+
+    `shapes` keeps the Keras variable order (names, export, iteration).  The MEMORY order is chosen for the data-parallel
+    all-reduce: conv kernels first, in the order their gradients complete in the backward pass (head, up6..up1,
+    down6..down1), then every small tensor (gamma/beta/bias) in one tail region.  Contiguous runs of kernels form the
+    gradient buckets that are all-reduced while the backward pass is still running; the tail region goes last.
+    Every tensor is 16-byte aligned."""
+
+    BUCKET_MIN = 4 * 1024 * 1024      # floats (16 MB): a bucket closes once it holds at least this much
 
     def __init__(self, shapes, device):
         self.shapes = OrderedDict(shapes)
         self.offsets = OrderedDict()
-        off = 0
-        for k, s in self.shapes.items():
+        kernels = [k for k in self.shapes if k.endswith(".kernel")]
+        small = [k for k in self.shapes if not k.endswith(".kernel")]
+        off, self.buckets, start, self.bucket_of = 0, [], 0, {}
+        for k in reversed(kernels):           # backward completion order
             self.offsets[k] = off
-            off += int(np.prod(s))
-            off = (off + 3) // 4 * 4          # keep every tensor 16-byte aligned
+            off += int(np.prod(self.shapes[k]))
+            off = (off + 3) // 4 * 4
+            self.bucket_of[k[:-7]] = len(self.buckets)
+            if off - start >= self.BUCKET_MIN:
+                self.buckets.append((start, off))
+                start = off
+        if off > start:
+            self.buckets.append((start, off))
+        self.bucket_last_layer = {}           # bucket index -> layer whose gradient completes it
+        for k in reversed(kernels):
+            self.bucket_last_layer[self.bucket_of[k[:-7]]] = k[:-7]
+        self.small_range = (off, off)
+        for k in small:
+            self.offsets[k] = off
+            off += int(np.prod(self.shapes[k]))
+            off = (off + 3) // 4 * 4
+        self.small_range = (self.small_range[0], off)
         self.numel = off
         self.params = torch.zeros(off, dtype=torch.float32, device=device)
         self.grads = torch.zeros(off, dtype=torch.float32, device=device)
@@ -223,6 +248,7 @@ class Pix2PixEngine:
         self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
         self.step_count = 0
         self.side = _SideStream(self.device, overlap_wgrad)
+        self._dp = None             # parallel.DataParallel of the step in flight
         self.refresh_weight_copies()
 
     # ------------------------------------------------------------------ parameters
@@ -463,6 +489,14 @@ class Pix2PixEngine:
         self.side.fork()
         with self.side.run():
             self._wgrad_impl(P, sid, name, N, lh, hi, lo, stride, dbias)
+            dp = self._dp
+            if dp is not None and sid == "G":
+                b = self.G.bucket_of[name]
+                if self.G.bucket_last_layer[b] == name:
+                    # every kernel gradient of this bucket has been issued on this stream: all-reduce it now,
+                    # concurrently with the rest of the backward pass
+                    lo_e, hi_e = self.G.buckets[b]
+                    dp.allreduce_async(self.G.grads[lo_e:hi_e])
 
     def _wgrad_impl(self, P, sid, name, N, lh, hi, lo, stride=2, dbias=None):
         lw = self.W[(sid, name)]
@@ -605,13 +639,14 @@ class Pix2PixEngine:
 
     # ------------------------------------------------------------------ train step (RGBA models)
     def train_step_rgba(self, source, real, lambda_l1, lambda_hist=None, masks=None, global_batch=None,
-                        apply_update=True, allreduce=None, hist_allreduce=None):
+                        apply_update=True, dp=None):
         """Pix2PixModel.train_step / Pix2PixHistogramModel (pix2pix_model.py:62-89,242-250).
         Returns a device tensor [g_total, g_adv, g_l1, g_hist, d_total, d_real, d_fake] (f32)."""
         B = int(source.shape[0])
         P = self.plan(B)
         S, ic = self.S, self.in_ch
         Bg = global_batch or B
+        self._dp = dp
         src_t, real_t = self._to_device(source, ic, B), self._to_device(real, ic, B)
         self._pack_source(P, src_t, with_disc=True)
         self._pack(P, real_t, P["dcat"].view(coff=0), ic)
@@ -627,14 +662,14 @@ class Pix2PixEngine:
                C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.losses, 0), _stream())
         g_extra = None
         if lambda_hist is not None:
-            g_extra = self._histogram_loss(P, B, Bg, lambda_hist, hist_allreduce)
+            g_extra = self._histogram_loss(P, B, Bg, lambda_hist, dp.allreduce_scalar_sum if dp is not None else None)
         P["skip_g_through_d"] = False
         self.discriminator_backward(P, B)
         L.call("p2p_tanh_l1_bwd", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), C.byref(real_view),
                C.byref(P["g_dcat"].gsrc()), C.byref(g_extra) if g_extra is not None else None,
                float(lambda_l1) * inv_l1, C.byref(P["dz"].view()), _stream())
         self.generator_backward(P)
-        return self._finish_step(P, lambda_l1, lambda_hist, apply_update, allreduce)
+        return self._finish_step(P, lambda_l1, lambda_hist, apply_update)
 
     def generator_backward(self, P):
         """Backward of UnetGenerator from dz (the gradient at the head's pre-activation)."""
@@ -694,10 +729,22 @@ class Pix2PixEngine:
                NULL, NULL, NULL, 0, self._nsplit(buf.n, buf.h, buf.c), _stream())
         return (1, 1)
 
-    def _finish_step(self, P, lambda_l1, lambda_hist, apply_update, allreduce):
+    def _reduce_tail(self):
+        """after the backward pass: the small-tensor tail of the generator gradients (gamma/beta/bias), the whole
+        discriminator gradient (36.9 KB) and the loss scalars; then wait for every bucket in flight."""
+        dp = self._dp
+        if dp is None:
+            return
+        lo_e, hi_e = self.G.small_range
+        dp.allreduce_async(self.G.grads[lo_e:hi_e])
+        dp.allreduce_async(self.D.grads)
+        dp.allreduce_async(self.losses)
+        dp.wait_all()
+        self._dp = None
+
+    def _finish_step(self, P, lambda_l1, lambda_hist, apply_update):
         self.side.join()
-        if allreduce is not None:
-            allreduce(self.G.grads, self.D.grads, self.losses)
+        self._reduce_tail()
         if apply_update:
             self.apply_adam()
         out = torch.empty(8, dtype=torch.float32, device=self.device)
@@ -761,7 +808,7 @@ class Pix2PixEngine:
 
     # ------------------------------------------------------------------ train step (indexed model)
     def train_step_indexed(self, source_idx, real_idx, lambda_segmentation, masks=None, global_batch=None,
-                           apply_update=True, allreduce=None):
+                           apply_update=True, dp=None):
         """Pix2PixIndexedModel.train_step (pix2pix_model.py:295-325).  source/real: int (B,S,S,1) palette indices.
         The discriminator sees un-normalised index images and the argmax blocks every gradient from D to G, so the
         generator learns from lambda_seg * CCE only (lambda_l1 is hard-wired to 0, :263).
@@ -771,6 +818,7 @@ class Pix2PixEngine:
         P = self.plan(B)
         S = self.S
         Bg = global_batch or B
+        self._dp = dp
         src_t = self._to_device(source_idx, 1, B, is_int=True)
         real_t = self._to_device(real_idx, 1, B, is_int=True)
         self._pack_source(P, src_t, with_disc=True)
@@ -789,8 +837,7 @@ class Pix2PixEngine:
         self.discriminator_backward(P, B)
         self.generator_backward(P)
         self.side.join()
-        if allreduce is not None:
-            allreduce(self.G.grads, self.D.grads, self.losses)
+        self._reduce_tail()
         if apply_update:
             self.apply_adam()
         out = torch.empty(8, dtype=torch.float32, device=self.device)

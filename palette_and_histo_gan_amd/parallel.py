@@ -9,8 +9,10 @@ sharding is derived in SURVEY.md 8e:
   * dgamma/dbeta sum over batch and space and ride in the same flat gradient buffer;
   * the histogram model's Hellinger loss is sqrt(sum over the GLOBAL batch)/B_global (histogram.py:88-89), so one
     extra scalar all-reduce of the local sum of squares sits between the histogram forward and backward.
-Collectives per step: all-reduce SUM of the flat generator gradient buffer (117.2 MB f32), of the discriminator
-gradient buffer (36.9 KB) and of the loss scalars.
+Collectives per step: all-reduce SUM of the flat generator gradient buffer (117.2 MB f32) in ~6 buckets of >= 16 MB
+that are issued asynchronously as soon as the weight-gradient kernels of a bucket have been launched (the flat buffer
+is laid out in backward completion order, engine.ParamStore) and so overlap the rest of the backward pass; then the
+small-tensor tail, the discriminator gradient buffer (36.9 KB) and the loss scalars.
 """
 import os
 
@@ -31,6 +33,17 @@ class DataParallel:
                 kw["device_id"] = self.device
             dist.init_process_group(backend=backend, **kw)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self._handles = []
+
+    def allreduce_async(self, t):
+        """SUM all-reduce of `t` in place, asynchronously: the collective is ordered after the work already issued on
+        the CURRENT stream and runs on the backend's own stream; wait_all() orders later work after it."""
+        self._handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait_all(self):
+        for h in self._handles:
+            h.wait()
+        self._handles = []
 
     def allreduce_grads(self, g_grads, d_grads, losses):
         """SUM over ranks, in place.  Loss partials are already scaled with the global counts."""

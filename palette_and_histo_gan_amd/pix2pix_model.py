@@ -70,16 +70,14 @@ class Pix2PixModel(S2SModel):
     # -- the hot path ----------------------------------------------------------------------------------------------
     def _dp(self):
         dp = self.data_parallel
-        if dp is None:
-            return 1, None, None
-        return dp.world, dp.allreduce_grads, dp.allreduce_scalar_sum
+        return (1, None) if dp is None else (dp.world, dp)
 
     def train_step(self, batch, step, update_steps):
         """pix2pix_model.py:62-89"""
         source_image, real_image = batch
-        world, allreduce, _ = self._dp()
+        world, dp = self._dp()
         out = self.engine.train_step_rgba(source_image, real_image, self.lambda_l1,
-                                          global_batch=len(source_image) * world, allreduce=allreduce)
+                                          global_batch=len(source_image) * world, dp=dp)
         g_loss, d_loss = (out[0], out[1], out[2]), (out[4], out[5], out[6])
         self._log(g_loss, d_loss, step, update_steps)
         return g_loss, d_loss
@@ -149,10 +147,9 @@ class Pix2PixHistogramModel(Pix2PixAugmentedModel):
 
     def train_step(self, batch, step, update_steps):
         source_image, real_image = batch
-        world, allreduce, hist_allreduce = self._dp()
+        world, dp = self._dp()
         out = self.engine.train_step_rgba(source_image, real_image, self.lambda_l1, lambda_hist=self.lambda_histogram,
-                                          global_batch=len(source_image) * world, allreduce=allreduce,
-                                          hist_allreduce=hist_allreduce)
+                                          global_batch=len(source_image) * world, dp=dp)
         g_loss, d_loss = (out[0], out[1], out[2], out[3]), (out[4], out[5], out[6])
         self._log(g_loss, d_loss, step, update_steps)
         return g_loss, d_loss
@@ -187,9 +184,9 @@ class Pix2PixIndexedModel(Pix2PixModel):
     def train_step(self, batch, step, update_steps):
         """pix2pix_model.py:295-325"""
         source_image, real_image, _ = batch
-        world, allreduce, _ = self._dp()
+        world, dp = self._dp()
         out = self.engine.train_step_indexed(source_image, real_image, self.lambda_segmentation,
-                                             global_batch=len(source_image) * world, allreduce=allreduce)
+                                             global_batch=len(source_image) * world, dp=dp)
         g_loss, d_loss = (out[0], out[1], out[2], out[3]), (out[4], out[5], out[6])
         self._log(g_loss, d_loss, step, update_steps)
         return g_loss, d_loss

@@ -104,7 +104,7 @@ def _dp_worker(rank, world, port, q):
     eng = E.Pix2PixEngine(4, 4, "tanh", 64, L.F32, device="cuda:0")
     eng.set_params({k: v.numpy() for k, v in Gp.items()}, {k: v.numpy() for k, v in Dp.items()})
     out = eng.train_step_rgba(src[lo:hi], tgt[lo:hi], 30.0, lambda_hist=1.0, masks=[m[lo:hi] for m in masks],
-                              global_batch=B, allreduce=comm.allreduce_grads, hist_allreduce=comm.allreduce_scalar_sum)
+                              global_batch=B, dp=comm)
     torch.cuda.synchronize()
     if rank == 0:
         q.put((out.cpu().numpy(), eng.G.grads.cpu().numpy(), eng.D.grads.cpu().numpy(), eng.G.params.cpu().numpy()))
