@@ -132,7 +132,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    comm = PAR.init_data_parallel(device) if world > 1 else None
+    # under torchrun (RANK set) the RCCL process group is created even for one rank, so the collective path is the
+    # same code at N = 1, 2, 4, 8
+    comm = PAR.init_data_parallel(device) if (world > 1 or "RANK" in os.environ) else None
 
     model, B, S, lam_l1, lam_hist, palette = CONFIGS[args.config]
     if args.batch:

@@ -80,7 +80,12 @@ int p2p_conv_direct(int op, int stride, int dtype, int N, int LH, int LW, int Cg
  * (p2p_norm_act_fwd / p2p_gsrc). */
 int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd,
               const p2p_tensor* hi, const p2p_tensor* lo, const void* w,
-              int splitk, float* slabs, void* stream);
+              int splitk, float* slabs, float* stat_part, void* stream);
+/* InstanceNorm statistics fused into the epilogue (splitk == 1): stat_part[N][slots][Cout][2] receives, per image and
+ * slot, the mean and the centred sum of squares of an equal share of that image's output pixels;
+ * slots = p2p_igemm_stat_slots(op, N, LH, LW, Cout) (0 = this shape cannot fuse them: pass stat_part = null and let
+ * p2p_norm_act_fwd compute them).  p2p_norm_act_fwd consumes them with ws = stat_part, nsplit = -slots. */
+int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols);
 
 /* Edge-layer form of the same kernel (Cin 1..8, the 36/33-channel concat, Cout 1..4; networks.py:46-48,57,75-78):
  * stride 1 or 2, any contraction width that fills whole 16-byte chunks (`cin_pad` = channels of the gathered
@@ -116,7 +121,8 @@ int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, 
  * null) scales kept values by 2.  Writes y into the (haloed, possibly channel-sliced) view `out`,
  * mean/rstd into stats[N][C][2] and, if raw_out != null, the summed raw tensor in `dtype`.
  * nsplit > 1 splits every image's pixel range over nsplit workgroups (two launches: partial sums to the f32
- * workspace ws, >= N*nsplit*C*2*4 bytes, then apply); nsplit <= 1 or ws == null = one launch. */
+ * workspace ws, >= N*nsplit*C*2*4 bytes, then apply); nsplit in {0, 1} or ws == null = one launch;
+ * nsplit < 0: ws holds -nsplit statistics slots per image written by p2p_igemm's epilogue (apply only). */
 int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C,
                      const void* raw, int raw_kind, int nslabs, long long slab_stride,
                      const float* gamma, const float* beta, float eps, int act, float alpha,

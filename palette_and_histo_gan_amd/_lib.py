@@ -29,7 +29,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> argtypes; every function returns int except the two noted below
 SIGNATURES = {
     "p2p_conv_direct": [_i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp, _vp, _vp],
-    "p2p_igemm": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
+    "p2p_igemm": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp, _vp],
     "p2p_igemm_edge": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_wgemm_edge": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
     "p2p_view_colsum": [_i, _i, _i, _i, _i, _TP, _vp, _vp],
@@ -63,6 +63,7 @@ SIGNATURES = {
     "p2p_argmax_lastdim": [_vp, _ll, _i, _vp, _vp],
 }
 SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
+           "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),
            "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong)}
 
 _lib = None

@@ -34,6 +34,9 @@ struct IgemmArgs {
     int si;              // input scale of op G (stride)
     int splitk, taps_per;
     int act; float alpha;
+    // fused InstanceNorm statistics (VEPI epilogue): per (image, slot, channel) the mean and the centred sum of squares
+    // of `stat_rows` consecutive output pixels of one image; slot = phase * tiles_per_image + tile_in_image
+    float* stat_part; int stat_rows; int stat_slots; int lgHW;
 };
 
 template <typename T> struct Frag;
@@ -63,8 +66,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int ks = blockIdx.z % a.splitk, phase = blockIdx.z / a.splitk;
+    // logical block order: N tile fastest, then phase / K split, then M tile: the blocks that gather the same input
+    // pixels (all output-channel tiles, all 4 sub-pixel phases) sit next to each other and share an XCD's L2
+    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int by = lin % gridDim.y, bz = (lin / gridDim.y) % gridDim.z, bx = lin / (gridDim.y * gridDim.z);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int ks = bz % a.splitk, phase = bz / a.splitk;
     const int ph = phase >> 1, pw = phase & 1;
     const int tap_begin = ks * a.taps_per;
     const int CBbytes = GEN ? a.Cc * 16 : (1 << a.lgCB);          // bytes per tap row
@@ -220,6 +228,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
                 }
             }
             __syncthreads();
+            if (a.stat_part && !to_slabs) {
+                // InstanceNorm statistics of this tile (networks.py:18,29), taken from the ROUNDED values the consumer
+                // will read back: two passes over the LDS tile (mean, then centred squares), per group of stat_rows rows.
+                constexpr int NP = 256 / BN;                       // row parts per column
+                float* scr = (float*)(smem + BM * RS);             // [NP][BN] scratch behind the tile
+                const int colL = tid % BN, part = tid / BN;
+                const int rows = a.stat_rows, ngrp = BM / rows;
+                for (int gI = 0; gI < ngrp; ++gI) {
+                    const int rbeg = gI * rows;
+                    float sacc = 0.f;
+                    for (int r = rbeg + part; r < rbeg + rows; r += NP) sacc += to_f32(*(const TO*)(smem + r * RS + colL * osz));
+                    scr[part * BN + colL] = sacc;
+                    __syncthreads();
+                    float mean = 0.f;
+#pragma unroll
+                    for (int q2 = 0; q2 < NP; ++q2) mean += scr[q2 * BN + colL];
+                    mean /= (float)rows;
+                    __syncthreads();
+                    float qacc = 0.f;
+                    for (int r = rbeg + part; r < rbeg + rows; r += NP) {
+                        float d = to_f32(*(const TO*)(smem + r * RS + colL * osz)) - mean;
+                        qacc += d * d;
+                    }
+                    scr[part * BN + colL] = qacc;
+                    __syncthreads();
+                    if (part == 0 && n0 + colL < a.ncols) {
+                        float m2 = 0.f;
+#pragma unroll
+                        for (int q2 = 0; q2 < NP; ++q2) m2 += scr[q2 * BN + colL];
+                        const int mrow = m0 + rbeg;
+                        const int img = mrow >> a.lgHW;
+                        const int tile_in_img = (mrow & ((1 << a.lgHW) - 1)) / rows;
+                        const int slot = phase * (a.stat_slots / (a.mode == 1 ? 4 : 1)) + tile_in_img;
+                        float* dst = a.stat_part + (((long long)img * a.stat_slots + slot) * a.ncols + n0 + colL) * 2;
+                        dst[0] = mean;
+                        dst[1] = m2;
+                    }
+                    __syncthreads();
+                }
+            }
             TO* obase = to_slabs ? (TO*)(a.slabs + (long long)ks * a.slab_stride) : (TO*)a.out;
             const int chunk = tid % CPR, r0 = tid / CPR;
             const int col = n0 + chunk * CE;
@@ -273,7 +321,7 @@ static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
     const int ctiles = (a.ncols + 31) / 32 * 32;
     dim3 grid((a.M + BM - 1) / BM, (ctiles + BN - 1) / BN, gz);
     size_t stage = 2 * (size_t)(BM + BN) * 128;
-    size_t epi = (size_t)BM * (BN * 4 + 16);           // f32 staging of the epilogue is the larger case
+    size_t epi = (size_t)BM * (BN * 4 + 16) + 4096;    // f32 staging of the epilogue is the larger case (+ stats scratch)
     size_t shm = vepi ? (stage > epi ? stage : epi) : stage;
     static bool attr_done[2] = {false, false};      // per template instantiation: allow > 64 KB of dynamic LDS
     if (!attr_done[vepi]) {
@@ -301,11 +349,13 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
     return p2p_check_launch("p2p_igemm");
 }
 
+extern "C" int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols);
+
 // Shared implementation.  C = channels of the gathered operand as laid out in `w` and read from the input
 // view (whole 16-byte chunks), w_rows = rows per weight tap slab (multiple of 32, >= the launched columns).
 static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, int C, int ncols, int w_rows,
                         const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias, int act,
-                        float alpha, int splitk, float* slabs, void* stream) {
+                        float alpha, int splitk, float* slabs, float* stat_part, void* stream) {
     const int esz = dtype == P2P_BF16 ? 2 : 4;
     IgemmArgs a;
     a.C = C; a.ncols = ncols; a.w_rows = w_rows;
@@ -347,12 +397,37 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
     const int osz = splitk > 1 ? 4 : esz, ce = 16 / osz;
     const bool vepi = ncols % ce == 0 && (a.out_ld * osz) % 16 == 0 &&
                       (splitk > 1 ? ((uintptr_t)slabs % 16) == 0 : ((uintptr_t)out->ptr % 16) == 0);
+    // fused statistics: whole tiles, each tile row group inside one image (see p2p_igemm_stat_slots)
+    a.stat_part = nullptr; a.stat_rows = 0; a.stat_slots = 0; a.lgHW = a.lgLW + a.lgLH;
+    if (stat_part) {
+        const int slots = p2p_igemm_stat_slots(op, N, LH, LW, ncols);
+        P2P_REQUIRE(slots > 0 && vepi && splitk == 1, "p2p_igemm: fused statistics not available for this shape (query p2p_igemm_stat_slots)");
+        const int ctl = (ncols + 31) / 32 * 32;
+        const int bm = (ctl % 128 == 0) ? 128 : ((long long)N * LH * LW >= 256 * 512 ? 256 : 128);
+        const int hw = LH * LW;
+        a.stat_part = stat_part;
+        a.stat_rows = hw < bm ? hw : bm;
+        a.stat_slots = slots;
+    }
     if (pow2) { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, false>(a, phases, vepi, st))); }
     else { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, true>(a, phases, vepi, st))); }
 }
 
+// Number of statistics slots per image that the fused epilogue writes for this launch shape, or 0 if the statistics
+// cannot be fused (ragged tiles): slot partials are (mean, centred sum of squares) over LH*LW*phases/slots pixels each.
+extern "C" int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols) {
+    const long long M = (long long)N * LH * LW;
+    const int ctl = (ncols + 31) / 32 * 32;
+    const int bm = (ctl % 128 == 0) ? 128 : (M >= 256 * 512 ? 256 : 128);
+    const int hw = LH * LW;
+    if (M % bm != 0) return 0;
+    if (!(hw % bm == 0 || bm % hw == 0)) return 0;
+    const int phases = op == P2P_OP_P ? 4 : 1;
+    return phases * (hw >= bm ? hw / bm : 1);
+}
+
 extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
-                         const p2p_tensor* lo, const void* w, int splitk, float* slabs, void* stream) {
+                         const p2p_tensor* lo, const void* w, int splitk, float* slabs, float* stat_part, void* stream) {
     P2P_REQUIRE(op == P2P_OP_G || op == P2P_OP_P, "p2p_igemm: op must be G or P");
     P2P_REQUIRE(N > 0 && LH > 0 && LW > 0, "p2p_igemm: bad shape");
     P2P_REQUIRE(Cg % 32 == 0 && Cd % 32 == 0 && Cg > 0 && Cd > 0, "p2p_igemm: Cg=%d, Cd=%d must be multiples of 32", Cg, Cd);
@@ -360,7 +435,7 @@ extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int C
     const p2p_tensor* in = op == P2P_OP_G ? hi : lo;
     const p2p_tensor* out = op == P2P_OP_G ? lo : hi;
     const int C = op == P2P_OP_G ? Cg : Cd, ncols = op == P2P_OP_G ? Cd : Cg;
-    return igemm_common(op, 2, dtype, N, LH, LW, C, ncols, ncols, in, out, w, nullptr, P2P_ACT_NONE, 0.f, splitk, slabs, stream);
+    return igemm_common(op, 2, dtype, N, LH, LW, C, ncols, ncols, in, out, w, nullptr, P2P_ACT_NONE, 0.f, splitk, slabs, stat_part, stream);
 }
 
 extern "C" int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols,
@@ -370,5 +445,5 @@ extern "C" int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int 
     P2P_REQUIRE(stride == 1 || stride == 2, "p2p_igemm_edge: stride must be 1 or 2");
     P2P_REQUIRE(N > 0 && LH > 0 && LW > 0 && cin_pad > 0, "p2p_igemm_edge: bad shape");
     P2P_REQUIRE(in && out && in->ptr && out->ptr && w, "p2p_igemm_edge: null pointer");
-    return igemm_common(op, stride, dtype, N, LH, LW, cin_pad, ncols, w_rows, in, out, w, bias, act, alpha, 1, nullptr, stream);
+    return igemm_common(op, stride, dtype, N, LH, LW, cin_pad, ncols, w_rows, in, out, w, bias, act, alpha, 1, nullptr, nullptr, stream);
 }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
                                                         float eps, int act, float alpha,
                                                         const unsigned char* __restrict__ mask, TView out,
                                                         T* __restrict__ raw_out, float* __restrict__ stats,
-                                                        float* __restrict__ ws) {
+                                                        float* __restrict__ ws, int nslots) {
     constexpr int VN = VecOf<T>::N;
     __shared__ float red[2][2048];      // [2][PR][CG], PR * CG = 256 * VN <= 2048
     const int n = blockIdx.x;
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
     float mu[VN], rs[VN], ga[VN], be[VN];
     if (gamma) {
         float sh[VN], t1[VN], t2[VN];
-        raw_vload<T>(raw, raw_kind, nslabs, slab, base, sh);        // image-wide shift: the first pixel's value
-        if (MODE != 2) {
+        if (MODE != 3) raw_vload<T>(raw, raw_kind, nslabs, slab, base, sh);        // image-wide shift: the first pixel's value
+        if (MODE < 2) {
             float s1[VN], s2[VN];
 #pragma unroll
             for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
                     }
                 return;
             }
-        } else {
+        } else if (MODE == 2) {
 #pragma unroll
             for (int k = 0; k < VN; ++k) {
                 t1[k] = 0.f; t2[k] = 0.f;
@@ -286,6 +286,31 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
                     t1[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 0];
                     t2[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 1];
                 }
+            }
+        } else {
+            // MODE 3: `ws` holds the conv epilogue's per-slot (mean, centred sum of squares) of equal-sized pixel groups
+            // (p2p_igemm stat_part, nslots groups per image): pooled mean and variance by the parallel-variance rule,
+            // computed once per workgroup (one thread per channel) and shared through LDS.
+            if (threadIdx.x < CG) {
+                const int cc = cg0 + threadIdx.x;
+                float ms = 0.f;
+                for (int i = 0; i < nslots; ++i) ms += ws[(((long long)n * nslots + i) * C + cc) * 2 + 0];
+                const float mall = ms / (float)nslots;
+                const float cnt = (float)HW / (float)nslots;
+                float m2 = 0.f;
+                for (int i = 0; i < nslots; ++i) {
+                    float mi = ws[(((long long)n * nslots + i) * C + cc) * 2 + 0];
+                    m2 += ws[(((long long)n * nslots + i) * C + cc) * 2 + 1] + cnt * (mi - mall) * (mi - mall);
+                }
+                red[0][threadIdx.x] = mall;
+                red[1][threadIdx.x] = m2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                sh[k] = red[0][vid * VN + k];     // shift := pooled mean, so t1 = 0 and t2 = pooled centred sum of squares
+                t1[k] = 0.f;
+                t2[k] = red[1][vid * VN + k];
             }
         }
 #pragma unroll
@@ -546,19 +571,31 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
             const int prr = 256 / vpp;
             int sp = nsplit < 1 ? 1 : nsplit;
             while (sp > 1 && (H * W + sp - 1) / sp < prr) sp >>= 1;       // every split keeps all pixel lanes busy
+            if (nsplit < 0 && gamma && ws) {
+                // statistics were produced by the conv epilogue (-nsplit slots per image in ws): apply only, and the
+                // pixel range can be split freely for parallelism
+                const int nslots = -nsplit;
+                int sp2 = 1;
+                while ((long long)N * (C / CG) * sp2 < 2048 && (H * W) / (sp2 * 2) >= prr && sp2 < 64) sp2 *= 2;
+                dim3 grid3(N, C / CG, sp2);
+                P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 3><<<grid3, 256, 0, st>>>(
+                                              H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
+                                              make_view(out), (T*)raw_out, stats, ws, nslots)));
+                return p2p_check_launch("p2p_norm_act_fwd");
+            }
             if (!ws || (long long)N * sp * C * 2 * 4 > ws_bytes) sp = gamma ? 1 : sp;
             dim3 grid(N, C / CG, sp);
             if (sp == 1 || !gamma) {
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 0><<<grid, 256, 0, st>>>(
                                               H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                              make_view(out), (T*)raw_out, stats, ws)));
+                                              make_view(out), (T*)raw_out, stats, ws, 0)));
             } else {
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 1><<<grid, 256, 0, st>>>(
                                               H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                              make_view(out), (T*)raw_out, stats, ws)));
+                                              make_view(out), (T*)raw_out, stats, ws, 0)));
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 2><<<grid, 256, 0, st>>>(
                                               H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                              make_view(out), (T*)raw_out, stats, ws)));
+                                              make_view(out), (T*)raw_out, stats, ws, 0)));
             }
             return p2p_check_launch("p2p_norm_act_fwd");
         }

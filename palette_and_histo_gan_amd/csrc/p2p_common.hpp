@@ -97,6 +97,15 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return s;
 }
 
+// XCD-aware block index (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with its
+// own L2, so the blocks b, b+8, b+16, ... share an L2.  This bijective remap hands every XCD one CONTIGUOUS range of the
+// logical block order, so blocks that the caller orders next to each other (same input pixels) hit the same L2.
+// Speed only: any placement gives the same results.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 #define P2P_DISPATCH_DTYPE(dtype, CALL)                         \
     do {                                                        \
         if ((dtype) == P2P_F32) { typedef float T; CALL; }      \

@@ -53,11 +53,16 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    // logical block order: (tap, g tile) fastest, then d tile, then pixel chunk -- all tiles of one pixel chunk read the
+    // same pixels, so they are kept on one XCD (measured before the remap: 7x the algorithmic HBM bytes, r01 PMC run)
+    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bx = lin % gridDim.x, by = (lin / gridDim.x) % gridDim.y, bz = lin / (gridDim.x * gridDim.y);
     const int gtiles = (a.Cg + BG - 1) / BG;
-    const int t = blockIdx.x / gtiles, g0 = (blockIdx.x % gtiles) * BG;
-    const int d0 = blockIdx.y * BD;
+    const int t = bx / gtiles, g0 = (bx % gtiles) * BG;
+    const int d0 = by * BD;
     const int kh = t >> 2, kw = t & 3;
-    const int mbeg = blockIdx.z * a.chunk;
+    const int mbeg = bz * a.chunk;
     const int mend = min(mbeg + a.chunk, a.M);
     const int nst = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
     const int s = a.stride;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
     }
 
     // D[row = g][col = d]
-    float* outp = a.part + ((long long)blockIdx.z * 16 + t) * a.Cg * a.Cd;
+    float* outp = a.part + ((long long)bz * 16 + t) * a.Cg * a.Cd;
     const int h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -385,6 +385,7 @@ class Pix2PixEngine:
         if not self.use_mfma:
             P["d_raw"] = DenseBuf(2 * B, h2, h2, 64, tdt, dev)
         P["nws"] = torch.empty(max(B, 2) * 16 * 1024 * 2, dtype=torch.float32, device=dev)   # norm split partials [N][16][C<=1024][2]
+        P["spart"] = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=dev)    # conv-epilogue statistics [N][slots][C][2]
         # split-K / wgrad workspaces
         P["slabs"] = torch.empty(self._max_slab_elems(B), dtype=torch.float32, device=dev)
         P["wws"] = torch.empty(self._max_wgrad_ws(B) // 4 + 4, dtype=torch.float32, device=dev)
@@ -451,7 +452,7 @@ class Pix2PixEngine:
 
     # ------------------------------------------------------------------ kernel wrappers
     def _conv(self, P, op, sid, name, N, lh, in_view, out_view, stride=2, ncols=None, bias=None, act=L.ACT_NONE,
-              tmp=None):
+              tmp=None, want_stats=False):
         """op G (gathers the hi view, writes lo) or op P (gathers the lo view, writes hi).  Returns (raw_kind,
         nslabs): the result is in the output view in the activation dtype (1, 1) or in the f32 split-K slabs
         P['slabs'] (2, nslabs).  `ncols` limits op P to the first ncols output channels."""
@@ -461,8 +462,15 @@ class Pix2PixEngine:
         if self.use_mfma and lw.main and stride == 2 and bias is None and act == L.ACT_NONE and ncols is None:
             sk = self._splitk(op, N, lh, cg, cd)
             w = _p(lw.wt) if op == L.OP_G else self._wn(sid, name)
+            slots = 0
+            if want_stats and sk == 1:      # InstanceNorm statistics fused into the GEMM epilogue
+                slots = L.lib().p2p_igemm_stat_slots(op, N, lh, lh, cd if op == L.OP_G else cg)
+                if N * slots * (cd if op == L.OP_G else cg) * 2 > P["spart"].numel():
+                    slots = 0
             L.call("p2p_igemm", op, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), w, sk,
-                   _p(P["slabs"]) if sk > 1 else NULL, _stream())
+                   _p(P["slabs"]) if sk > 1 else NULL, _p(P["spart"]) if slots else NULL, _stream())
+            if slots:
+                return (1, 1, slots)
             return (1, 1) if sk == 1 else (2, sk)
         if self.use_mfma:
             if op == L.OP_G:
@@ -528,9 +536,14 @@ class Pix2PixEngine:
         return sp
 
     def _norm_fwd(self, P, N, res, c, raw_buf, rk, gamma, beta, act, mask, out_view, stats):
-        raw_kind, nslabs = rk
+        raw_kind, nslabs = rk[0], rk[1]
         raw = raw_buf.ptr() if raw_kind == 1 else _p(P["slabs"])
         slab = N * res * res * c
+        if len(rk) == 3:      # statistics already produced by the conv epilogue: apply-only pass
+            L.call("p2p_norm_act_fwd", self.dtype, N, res, res, c, raw, 1, 1, 0, gamma, beta, IN_EPS, act, LEAKY_ALPHA,
+                   _p(mask) if mask is not None else NULL, C.byref(out_view), NULL, _p(stats),
+                   _p(P["spart"]), P["spart"].numel() * 4, -rk[2], _stream())
+            return
         L.call("p2p_norm_act_fwd", self.dtype, N, res, res, c, raw, raw_kind, nslabs, slab,
                gamma if gamma is not None else NULL, beta if beta is not None else NULL, IN_EPS, act, LEAKY_ALPHA,
                _p(mask) if mask is not None else NULL, C.byref(out_view),
@@ -595,7 +608,7 @@ class Pix2PixEngine:
             if i == 1:      # no norm (networks.py:58): LeakyReLU fused in the conv epilogue
                 self._conv(P, L.OP_G, "G", "down1", B, res, src_view, out_view, act=L.ACT_LEAKY, tmp=P["rd"].get(1))
             else:
-                rk = self._conv(P, L.OP_G, "G", f"down{i}", B, res, src_view, P["rd"][i].view())
+                rk = self._conv(P, L.OP_G, "G", f"down{i}", B, res, src_view, P["rd"][i].view(), want_stats=True)
                 self._norm_fwd(P, B, res, f, P["rd"][i], rk, self.G.p(f"down{i}.gamma"), self.G.p(f"down{i}.beta"),
                                L.ACT_LEAKY, None, out_view, P["sd"][i])
             src_view = out_view
@@ -603,7 +616,7 @@ class Pix2PixEngine:
         lo_view = P["a6"].view()
         for i, f in enumerate(UP_FILTERS, start=1):
             lh = S // 64 * 2 ** (i - 1)
-            rk = self._conv(P, L.OP_P, "G", f"up{i}", B, lh, lo_view, P["ru"][i].view())
+            rk = self._conv(P, L.OP_P, "G", f"up{i}", B, lh, lo_view, P["ru"][i].view(), want_stats=True)
             mask = None
             if UP_DROPOUT[i - 1]:
                 mask = P["mask"][i]

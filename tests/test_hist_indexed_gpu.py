@@ -112,7 +112,8 @@ def test_argmax_is_bit_exact_with_engineered_ties():
         p[r, i] = p[r, j] = p[r].max() * 1.5
     p[5, :] = 1.0 / Cn                            # fully uniform row -> index 0
     got = torch.empty(M, dtype=torch.int32, device=U.DEV)
-    L.call("p2p_argmax_lastdim", U.ptr(U.dev(p)), M, Cn, U.ptr(got), U.stream())
+    p_d = U.dev(p)
+    L.call("p2p_argmax_lastdim", U.ptr(p_d), M, Cn, U.ptr(got), U.stream())
     want = torch.argmax(torch.tensor(p), dim=-1).to(torch.int32).numpy()      # tf.argmax semantics: first maximum
     want_np = np.argmax(p, axis=-1).astype(np.int32)
     assert np.array_equal(want, want_np)

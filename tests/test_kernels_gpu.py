@@ -74,7 +74,8 @@ def test_igemm_ops_G_and_P(dtype, n, lh, cg, cd, splitk):
     hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
     wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
     wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
-    L.call("p2p_weight_prep", dtype, U.ptr(U.dev(w.reshape(-1))), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
+    w_d = U.dev(w.reshape(-1))
+    L.call("p2p_weight_prep", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
     assert np.array_equal(wn.float().cpu().numpy().reshape(16, cg, cd), w.reshape(16, cg, cd))
     assert np.array_equal(wt.float().cpu().numpy().reshape(16, cd, cg), w.reshape(16, cg, cd).transpose(0, 2, 1))
     esz = 2 if dtype == L.BF16 else 4
@@ -89,7 +90,7 @@ def test_igemm_ops_G_and_P(dtype, n, lh, cg, cd, splitk):
         slabs = torch.full((max(sk, 1) * int(np.prod(shape)),), float("nan"), dtype=torch.float32, device=U.DEV)
         hv, lv = (hi_b.view(), out.view()) if op == L.OP_G else (out.view(), lo_b.view())
         L.call("p2p_igemm", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn),
-               sk, U.ptr(slabs) if sk > 1 else None, U.stream())
+               sk, U.ptr(slabs) if sk > 1 else None, None, U.stream())
         got = U.dense_to_np(out) if sk == 1 else slabs.view(sk, *shape).sum(0).cpu().numpy()
         tol = OUT_TOL[dtype] if sk == 1 else 2e-5
         assert U.rel_err(got, ref) < tol, (op, sk)
@@ -247,7 +248,7 @@ def test_dropout_mask_is_fair_and_reproducible():
 def test_bad_arguments_fail_loudly():
     t = L.Tensor(0, 0, 0, 0)
     with pytest.raises(L.P2PError):
-        L.call("p2p_igemm", L.OP_G, L.BF16, 1, 4, 4, 48, 64, C.byref(t), C.byref(t), None, 1, None, None)
+        L.call("p2p_igemm", L.OP_G, L.BF16, 1, 4, 4, 48, 64, C.byref(t), C.byref(t), None, 1, None, None, None)
     with pytest.raises(L.P2PError):
         L.call("p2p_conv_direct", 7, 2, L.F32, 1, 4, 4, 4, 4, C.byref(t), C.byref(t), None, None, None, None, None)
 
@@ -274,12 +275,14 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride):
     hi_b, lo_b = _pad_view_input(hi, hi_pad, dtype), _pad_view_input(lo, lo_pad, dtype)
     wt = torch.zeros(16 * E.up32(cd) * hi_pad, dtype=U.tdt(dtype), device=U.DEV)
     wn = torch.zeros(16 * E.up32(cg) * lo_pad, dtype=U.tdt(dtype), device=U.DEV)
-    L.call("p2p_weight_prep_pad", dtype, U.ptr(U.dev(w.reshape(-1))), cg, cd, U.ptr(wn), E.up32(cg), lo_pad,
+    w_d = U.dev(w.reshape(-1))
+    L.call("p2p_weight_prep_pad", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), E.up32(cg), lo_pad,
            U.ptr(wt), E.up32(cd), hi_pad, U.stream())
     # op G with bias + LeakyReLU into a channel slice of a wider haloed buffer
     out_g = E.HaloBuf(n, lh, lh, cd + 8, dtype, U.DEV)
+    bias_d = U.dev(bias)
     L.call("p2p_igemm_edge", L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd, E.up32(cd), C.byref(hi_b.view()),
-           C.byref(out_g.view(coff=8)), U.ptr(wt), U.ptr(U.dev(bias)), L.ACT_LEAKY, 0.3, U.stream())
+           C.byref(out_g.view(coff=8)), U.ptr(wt), U.ptr(bias_d), L.ACT_LEAKY, 0.3, U.stream())
     want = g_ref + bias
     want = np.where(want > 0, want, 0.3 * want)
     got = U.halo_to_np(out_g)
@@ -304,3 +307,44 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride):
     db = torch.empty(cd, dtype=torch.float32, device=U.DEV)
     L.call("p2p_view_colsum", dtype, n, lh, lh, cd, C.byref(lo_b.view()), U.ptr(db), U.stream())
     assert U.rel_err(db.cpu().numpy(), lo.astype(np.float64).sum(axis=(0, 1, 2))) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("op,n,lh,cg,cd", [(L.OP_G, 8, 8, 64, 128), (L.OP_P, 8, 8, 64, 128), (L.OP_G, 4, 16, 32, 64),
+                                            (L.OP_P, 64, 2, 128, 256), (L.OP_P, 128, 32, 32, 128)])
+def test_igemm_fused_instance_norm_statistics(dtype, op, n, lh, cg, cd):
+    """InstanceNorm statistics produced by the GEMM epilogue (slot partials pooled by the parallel-variance rule) and
+    consumed by the apply-only norm pass == the unfused path == the oracle."""
+    rng = np.random.default_rng(17)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, 2, dtype)
+    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
+    wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    w_d = U.dev(w.reshape(-1))
+    L.call("p2p_weight_prep", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
+    ncols = cd if op == L.OP_G else cg
+    res = lh if op == L.OP_G else 2 * lh
+    slots = L.lib().p2p_igemm_stat_slots(op, n, lh, lh, ncols)
+    assert slots > 0
+    out = E.DenseBuf(n, res, res, ncols, U.tdt(dtype), U.DEV)
+    spart = torch.full((n * slots * ncols * 2,), float("nan"), dtype=torch.float32, device=U.DEV)
+    hv, lv = (hi_b.view(), out.view()) if op == L.OP_G else (out.view(), lo_b.view())
+    L.call("p2p_igemm", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn), 1, None,
+           U.ptr(spart), U.stream())
+    x = U.dense_to_np(out).astype(np.float64)                 # the rounded values the statistics must describe
+    sp = spart.view(n, slots, ncols, 2).cpu().numpy().astype(np.float64)
+    cnt = res * res / slots
+    mean = sp[..., 0].mean(1)
+    m2 = sp[..., 1].sum(1) + cnt * ((sp[..., 0] - mean[:, None]) ** 2).sum(1)
+    np.testing.assert_allclose(mean, x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5 * np.abs(x).max())
+    np.testing.assert_allclose(m2 / (res * res), x.var(axis=(1, 2)), rtol=2e-4)
+    gamma = (1 + 0.2 * rng.normal(size=ncols)).astype(np.float32)
+    beta = (0.2 * rng.normal(size=ncols)).astype(np.float32)
+    y = E.HaloBuf(n, res, res, ncols, dtype, U.DEV)
+    stats = torch.empty((n, ncols, 2), dtype=torch.float32, device=U.DEV)
+    g_d, b_d = U.dev(gamma), U.dev(beta)          # keep the device tensors alive across the launch
+    L.call("p2p_norm_act_fwd", dtype, n, res, res, ncols, out.ptr(), 1, 1, 0, U.ptr(g_d), U.ptr(b_d), 1e-3,
+           L.ACT_RELU, 0.3, None, C.byref(y.view()), None, U.ptr(stats), U.ptr(spart), spart.numel() * 4, -slots, U.stream())
+    want = torch.relu(rg.instance_norm(torch.tensor(x), torch.tensor(gamma, dtype=F64), torch.tensor(beta, dtype=F64))).numpy()
+    assert U.rel_err(U.halo_to_np(y), want) < OUT_TOL[dtype]
+    np.testing.assert_allclose(stats[..., 0].cpu().numpy(), x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5 * np.abs(x).max())

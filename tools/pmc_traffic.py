@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Reduces two rocprofv3 --pmc runs (FETCH_SIZE and WRITE_SIZE, separate passes as the TCC slots require) of
+`bench.py` to HBM bytes per launch per kernel family.  Units and gfx950 correction follow MI355X_MICROARCH.md (HBM):
+both counters are in KiB; FETCH_SIZE reports half of the bytes of a wide coalesced stream, so it is doubled.
+
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+FAMILIES = {"igemm_kernel": "p2p_igemm", "wgemm_kernel": "p2p_wgemm", "norm_act_fwd_vec": "p2p_norm_act_fwd",
+            "norm_act_bwd_vec": "p2p_norm_act_bwd", "adam_flat_dev_kernel": "p2p_adam_flat_dev",
+            "weight_prep_kernel": "p2p_weight_prep_pad", "rgbuv_hist_fwd_kernel": "p2p_rgbuv_hist_fwd",
+            "rgbuv_hist_bwd_kernel": "p2p_rgbuv_hist_hellinger_bwd"}
+
+
+def load(folder, counter):
+    per = defaultdict(lambda: [0.0, 0])
+    files = glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no counter_collection.csv under {folder}")
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row.get("Kernel_Name", "")
+                fam = next((v for k, v in FAMILIES.items() if k in name), None)
+                if fam is None:
+                    continue
+                # GEN (edge) instantiations of igemm are a different entry point
+                if fam == "p2p_igemm" and ("Lb1ELb" in name or ", true," in name):
+                    fam = "p2p_igemm_edge"
+                per[fam][0] += float(row["Counter_Value"])
+                per[fam][1] += 1
+    return per
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    res = {}
+    for fam in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(fam, [0.0, 0])
+        w, nw = write.get(fam, [0.0, 0])
+        res[fam] = {"launches_fetch_pass": nf, "launches_write_pass": nw,
+                    "fetch_bytes_per_launch": (f / nf) * 1024 * 2 if nf else None,      # gfx950: FETCH_SIZE counts 64 B per 128 B request
+                    "write_bytes_per_launch": (w / nw) * 1024 if nw else None}
+        if nf and nw:
+            res[fam]["hbm_bytes_per_launch"] = res[fam]["fetch_bytes_per_launch"] + res[fam]["write_bytes_per_launch"]
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --config c2, "
+                         "KiB units, FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)", "kernels": res}, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
