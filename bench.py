@@ -91,7 +91,7 @@ def kernel_profile(eng, run_step, n_steps=3):
     L.call = timed
     E.L.call = timed
     side_was = eng.side.enabled
-    eng.side.enabled = False          # serialise everything on the launch stream so that each event pair brackets its kernel
+    eng.side.enabled = eng.side_hist.enabled = False   # serialise everything on the launch stream so that each event pair brackets its kernel
     try:
         for _ in range(n_steps):
             run_step()
@@ -99,7 +99,7 @@ def kernel_profile(eng, run_step, n_steps=3):
     finally:
         L.call = orig
         E.L.call = orig
-        eng.side.enabled = side_was
+        eng.side.enabled = eng.side_hist.enabled = side_was
     agg = {}
     for name, args, a, b in records:
         key = name

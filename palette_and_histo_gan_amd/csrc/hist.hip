@@ -18,7 +18,9 @@
 #define INV_SIGMA2 2500.0f    // 1 / 0.02^2  (histogram.py:36,54)
 
 __device__ __forceinline__ float hist_center(int i) { return -3.0f + (float)i * (6.0f / 63.0f); }   // linspace(-3,3,64)
-__device__ __forceinline__ float iq_kernel(float t) { return 1.0f / (1.0f + t * t * INV_SIGMA2); }  // histogram.py:26-27
+// inverse-quadratic kernel 1/(1 + t^2/sigma^2) (histogram.py:26-27).  v_rcp_f32 (1 ulp) instead of the IEEE division
+// sequence: the kernel evaluations are half of the forward kernel's instruction stream.
+__device__ __forceinline__ float iq_kernel(float t) { return __builtin_amdgcn_rcpf(fmaf(t * t, INV_SIGMA2, 1.0f)); }
 
 // log-chroma coordinates of pixel p for component c: (comp, p1, p2) = (R,G,B), (G,R,B), (B,R,G)   (histogram.py:72-74)
 __device__ __forceinline__ void comp_order(int c, int& a, int& p1, int& p2) {

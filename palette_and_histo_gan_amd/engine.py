@@ -248,6 +248,7 @@ class Pix2PixEngine:
         self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
         self.step_count = 0
         self.side = _SideStream(self.device, overlap_wgrad)
+        self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
         self.refresh_weight_copies()
 
@@ -663,21 +664,29 @@ class Pix2PixEngine:
         src_t, real_t = self._to_device(source, ic, B), self._to_device(real, ic, B)
         self._pack_source(P, src_t, with_disc=True)
         self._pack(P, real_t, P["dcat"].view(coff=0), ic)
+        if lambda_hist is not None:
+            self._hist_real_early(P, B)
         self.generator_forward(P, masks)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
         inv_l1 = 1.0 / (Bg * S * S * self.out_ch)
         L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
                C.byref(fake_view), inv_l1, _p(self.losses, 3), _stream())
+        g_extra = None
+        if lambda_hist is not None:
+            # the histogram loss only needs `fake`: its kernels (f32 MFMA, ~1.8 ms at B=256) run on the side stream,
+            # concurrently with the discriminator forward/backward, and are joined before the tanh backward
+            self.side_hist.fork()
+            with self.side_hist.run():
+                g_extra = self._histogram_loss(P, B, Bg, lambda_hist, dp.allreduce_scalar_sum if dp is not None else None)
         self.discriminator_forward(P, 2 * B)
         h2 = S // 2
         inv_bce = 1.0 / (Bg * h2 * h2)
         L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), inv_bce,
                C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.losses, 0), _stream())
-        g_extra = None
-        if lambda_hist is not None:
-            g_extra = self._histogram_loss(P, B, Bg, lambda_hist, dp.allreduce_scalar_sum if dp is not None else None)
         P["skip_g_through_d"] = False
         self.discriminator_backward(P, B)
+        if lambda_hist is not None:
+            self.side_hist.join()
         L.call("p2p_tanh_l1_bwd", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), C.byref(real_view),
                C.byref(P["g_dcat"].gsrc()), C.byref(g_extra) if g_extra is not None else None,
                float(lambda_l1) * inv_l1, C.byref(P["dz"].view()), _stream())
@@ -782,16 +791,11 @@ class Pix2PixEngine:
         The loss is sqrt(sum over the GLOBAL batch)/B_global, so under data parallelism the local sum of squares is
         all-reduced between the forward and the backward kernels."""
         S = self.S
-        if "h_real" not in P:
-            dev = self.device
-            P["h_real"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
-            P["h_fake"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
-            P["h_gh"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
-            P["h_tot"] = torch.empty((2, B), dtype=torch.float32, device=dev)
-            P["h_sq"] = torch.zeros(4, dtype=torch.float32, device=dev)
-            P["h_dimg"] = torch.empty(3 * B * S * S * 4, dtype=torch.float32, device=dev)
+        self._hist_buffers(P, B)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
-        L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(real_view), _p(P["h_real"]), _stream())
+        if not P.get("h_real_done"):
+            L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(real_view), _p(P["h_real"]), _stream())
+        P["h_real_done"] = False
         L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(fake_view), _p(P["h_fake"]), _stream())
         L.call("p2p_hellinger_fwd", _p(P["h_real"]), _p(P["h_fake"]), B, _p(P["h_tot"][0]), _p(P["h_tot"][1]),
                _p(P["h_sq"]), _stream())
@@ -804,6 +808,26 @@ class Pix2PixEngine:
         L.call("p2p_rgbuv_hist_hellinger_bwd", self.dtype, B, S, S, C.byref(fake_view), _p(P["h_real"]), _p(P["h_fake"]),
                _p(P["h_tot"][0]), _p(P["h_tot"][1]), _p(P["h_sq"]), coef, _p(P["h_gh"]), _p(P["h_dimg"]), _stream())
         return L.GSrc(P["h_dimg"].data_ptr(), 2, 3, B * S * S * 4, 4, 0)
+
+    def _hist_buffers(self, P, B):
+        if "h_real" in P:
+            return
+        dev, S = self.device, self.S
+        P["h_real"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
+        P["h_fake"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
+        P["h_gh"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
+        P["h_tot"] = torch.empty((2, B), dtype=torch.float32, device=dev)
+        P["h_sq"] = torch.zeros(4, dtype=torch.float32, device=dev)
+        P["h_dimg"] = torch.empty(3 * B * S * S * 4, dtype=torch.float32, device=dev)
+
+    def _hist_real_early(self, P, B):
+        """histogram of the REAL image (no dependence on the generator): issued on the histogram stream right after the
+        batch is packed, so its f32-MFMA work overlaps the generator forward."""
+        self._hist_buffers(P, B)
+        self.side_hist.fork()
+        with self.side_hist.run():
+            L.call("p2p_rgbuv_hist_fwd", self.dtype, B, self.S, self.S, C.byref(P["dcat"].view(coff=0)), _p(P["h_real"]), _stream())
+        P["h_real_done"] = True
 
     def rgbuv_histogram(self, image):
         """histogram.calculate_rgbuv_histogram (histogram.py:35-81) of a dense f32 (B,S,S,4) batch in [-1,1]:
