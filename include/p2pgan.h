@@ -110,6 +110,14 @@ int p2p_wgemm_edge(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd,
                    const p2p_tensor* hi, const p2p_tensor* lo, float* dw,
                    int msplit, void* workspace, void* stream);
 
+/* LDS-resident form for the edge layers (Cg, Cd <= 64 with at most two 32x32 tiles, LW in {16,32,64}): every strip of
+ * pixels is staged once and all 16 taps are contracted out of LDS, so HBM traffic = the algorithmic bytes.
+ * p2p_wgrad_small_blocks returns the number of f32 partial slabs the call needs in `workspace`
+ * (blocks * 16*Cg*Cd floats), or 0 if the shape is not supported (use p2p_wgemm_edge). */
+int p2p_wgrad_small_blocks(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld);
+int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd,
+                    const p2p_tensor* hi, const p2p_tensor* lo, float* dw, void* workspace, void* stream);
+
 /* out[c] = sum over all pixels of v[n,y,x,c] (f32): bias gradients of the stride-1 heads. */
 int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, void* stream);
 

@@ -32,6 +32,7 @@ SIGNATURES = {
     "p2p_igemm": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp, _vp],
     "p2p_igemm_edge": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_wgemm_edge": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
+    "p2p_wgrad_small": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp],
     "p2p_view_colsum": [_i, _i, _i, _i, _i, _TP, _vp, _vp],
     "p2p_act_bwd": [_i, _i, _i, _i, _i, _TP, _GP, _GP, _f, _TP, _vp],
     "p2p_weight_prep_pad": [_i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
@@ -64,6 +65,7 @@ SIGNATURES = {
 }
 SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
            "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),
+           "p2p_wgrad_small_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong)}
 
 _lib = None

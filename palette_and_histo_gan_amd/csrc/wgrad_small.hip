@@ -1,0 +1,243 @@
+// Weight gradient of the edge layers (networks.py:46-48,57,75-78: 4/8 -> 64, 36/33 -> 4, 64 -> 1 channels):
+//     dW[t][g][d] = sum_{n,y,x} hi[n, s*y+kh-1, s*x+kw-1, g] * lo[n, y, x, d]
+// The output is tiny (1 K - 8 K values) and the reduction runs over up to 2^20 pixels, so this is a streaming
+// reduction, HBM-bound in principle.  The general kernel (wgemm.hip) re-stages the pixels once per tap; here one
+// workgroup owns a strip of output rows of one image, brings the hi strip (with its halo) and the lo strip into LDS
+// ONCE and contracts all 16 taps out of LDS: bytes from HBM = the algorithmic bytes.
+//   * 8 waves; wave w owns taps 2w, 2w+1 and all (GT x DT = 2) 32x32 MFMA tiles of them -> 4 accumulators;
+//   * bf16: MFMA operands come from ds_read_b64_tr_b16 with PER-LANE row addresses (the 4 "rows" of a transposed
+//     read are the 4 pixels s*x+kw-1 apart in the strip, so stride-2 gathers cost nothing);
+//     f32: ds_read_b32 (one pixel per lane, v_mfma_f32_32x32x2_f32, exact);
+//   * channel counts below 32 read past the pixel into the next pixel's bytes (finite), masked at the store;
+//   * each workgroup accumulates over several strips and writes one f32 partial; a fixed-order reduction follows
+//     (deterministic, no float atomics).
+#include "p2p_common.hpp"
+
+struct WsArgs {
+    const char* hi; long long hi_img; int hi_row; int hi_ld;
+    const char* lo; long long lo_img; int lo_row; int lo_ld;
+    float* part;                   // [nblocks][16][Cg][Cd]
+    int N, LH, LW, Cg, Cd;
+    int TH;                        // lo rows per strip
+    int strips_per_img, nstrips;   // LH / TH, N * strips_per_img
+};
+
+__device__ __forceinline__ void glds16s(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename T, int S, int GT, int DT>
+__global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
+    constexpr int ESZ = sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TW = a.LW, TH = a.TH;
+    const int RH = S * TH + 3, RW = S * TW + 3;                 // hi strip incl. halo, pixels
+    const int hpB = a.hi_ld * ESZ, lpB = a.lo_ld * ESZ;         // pixel bytes (multiples of 16)
+    const int hrowB = RW * hpB;                                  // bytes per strip row in LDS (= contiguous HBM run)
+    const int hi_bytes = RH * hrowB;
+    const int lrowB = TW * lpB;
+    char* hiL = smem;
+    char* loL = smem + ((hi_bytes + 15) & ~15) + 256;           // slack: short pixels are over-read by up to 64 B
+
+    f32x16 acc[2][GT][DT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < GT; ++i)
+#pragma unroll
+            for (int j = 0; j < DT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+
+    for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x) {
+        const int n = strip / a.strips_per_img, y0 = (strip % a.strips_per_img) * TH;
+        __syncthreads();      // previous strip fully consumed
+        // ---- stage the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
+        const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row;
+        for (int cI = wave * 64; cI < hchunks; cI += 512) {
+            int ci = cI + lane;
+            if (ci < hchunks) {
+                int rr = ci / hchunks_row, cc = ci - rr * hchunks_row;
+                const char* src = a.hi + ((long long)n * a.hi_img + (long long)(S * y0 - 1 + rr) * a.hi_row - 1) * hpB + cc * 16;
+                glds16s(src, hiL + cI * 16);       // wave-uniform base + lane*16
+            }
+        }
+        const int lchunks_row = lrowB >> 4, lchunks = TH * lchunks_row;
+        for (int cI = wave * 64; cI < lchunks; cI += 512) {
+            int ci = cI + lane;
+            if (ci < lchunks) {
+                int rr = ci / lchunks_row, cc = ci - rr * lchunks_row;
+                const char* src = a.lo + ((long long)n * a.lo_img + (long long)(y0 + rr) * a.lo_row) * lpB + cc * 16;
+                glds16s(src, loL + cI * 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- contract: k-steps of 16 (bf16) / 2 (f32) consecutive lo pixels of one row -------------------------------
+        if constexpr (ESZ == 2) {
+            const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+            const int chB = (16 * (grp & 1) + 4 * p) * 2;            // byte offset of this lane's 4 channels inside a 32-channel tile
+            for (int yy = 0; yy < TH; ++yy) {
+                for (int x0 = 0; x0 < TW; x0 += 16) {
+                    bf16x8 bfr[DT];
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) {
+                        s16x4 r[2];
+#pragma unroll
+                        for (int rd = 0; rd < 2; ++rd) {
+                            int x = x0 + 8 * (grp >> 1) + 4 * rd + q;
+                            int off = (yy * TW + x) * lpB + j * 64 + chB;
+                            r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loL + off));
+                        }
+                        union { s16x4 h[2]; bf16x8 v; } u;
+                        u.h[0] = r[0]; u.h[1] = r[1];
+                        bfr[j] = u.v;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int tap = wave * 2 + t, kh = tap >> 2, kw = tap & 3;
+#pragma unroll
+                        for (int i = 0; i < GT; ++i) {
+                            s16x4 r[2];
+#pragma unroll
+                            for (int rd = 0; rd < 2; ++rd) {
+                                int x = x0 + 8 * (grp >> 1) + 4 * rd + q;
+                                int off = ((S * yy + kh) * RW + S * x + kw) * hpB + i * 64 + chB;
+                                r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiL + off));
+                            }
+                            union { s16x4 h[2]; bf16x8 v; } u;
+                            u.h[0] = r[0]; u.h[1] = r[1];
+#pragma unroll
+                            for (int j = 0; j < DT; ++j)
+                                acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, bfr[j], acc[t][i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            const int kl = lane >> 5, cl = lane & 31;
+            for (int yy = 0; yy < TH; ++yy) {
+                for (int x0 = 0; x0 < TW; x0 += 2) {
+                    const int x = x0 + kl;
+                    float bfr[DT];
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) bfr[j] = *(const float*)(loL + (yy * TW + x) * lpB + (j * 32 + cl) * 4);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int tap = wave * 2 + t, kh = tap >> 2, kw = tap & 3;
+#pragma unroll
+                        for (int i = 0; i < GT; ++i) {
+                            float af = *(const float*)(hiL + ((S * yy + kh) * RW + S * x + kw) * hpB + (i * 32 + cl) * 4);
+#pragma unroll
+                            for (int j = 0; j < DT; ++j)
+                                acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bfr[j], acc[t][i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- partial store: D[row = g][col = d] ------------------------------------------------------------------------
+    float* outp = a.part + (long long)blockIdx.x * 16 * a.Cg * a.Cd;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tap = wave * 2 + t;
+#pragma unroll
+        for (int i = 0; i < GT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int g = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (g >= a.Cg) continue;
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    int d = j * 32 + (lane & 31);
+                    if (d < a.Cd) outp[((long long)tap * a.Cg + g) * a.Cd + d] = acc[t][i][j][e];
+                }
+            }
+    }
+}
+
+__global__ void ws_slab_sum_kernel(const float* __restrict__ part, int nslabs, int n, float* __restrict__ out) {
+    // one workgroup per 64 outputs; 4 slab groups per output reduced through LDS (fixed order)
+    __shared__ float red[4][64];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (o < n)
+        for (int k = sg; k < nslabs; k += 4) s += part[(long long)k * n + o];
+    red[sg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sg == 0 && o < n) out[o] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// Applicability / workspace of the LDS-resident form.  Returns the number of partial slabs (workgroups) or 0.
+extern "C" int p2p_wgrad_small_blocks(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    if (Cg > 64 || Cd > 64 || ((Cg + 31) / 32) * ((Cd + 31) / 32) > 2) return 0;
+    if ((LW & (LW - 1)) || LW < 16 || LW > 64) return 0;
+    if ((hi_ld * esz) % 16 || (lo_ld * esz) % 16) return 0;
+    int TH = 512 / LW;
+    if (TH > 8) TH = 8;
+    if (TH > LH) TH = LH;
+    if (LH % TH) return 0;
+    const long long hi_bytes = (long long)(stride * TH + 3) * (stride * LW + 3) * hi_ld * esz;
+    const long long lo_bytes = (long long)TH * LW * lo_ld * esz;
+    if (hi_bytes + lo_bytes + 1024 > 150 * 1024) return 0;
+    long long strips = (long long)N * (LH / TH);
+    return (int)(strips < 512 ? strips : 512);
+}
+
+template <typename T>
+static int ws_launch(WsArgs& a, int stride, int nblocks, size_t shm, hipStream_t st) {
+    const int gt = (a.Cg + 31) / 32, dt = (a.Cd + 31) / 32;
+#define WS_GO(S_, G_, D_)                                                                                              \
+    do {                                                                                                               \
+        static bool done = false;                                                                                      \
+        if (!done) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)wgrad_small_kernel<T, S_, G_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            done = true;                                                                                               \
+        }                                                                                                              \
+        wgrad_small_kernel<T, S_, G_, D_><<<dim3(nblocks), dim3(512), shm, st>>>(a);                                   \
+    } while (0)
+    if (stride == 1) {
+        if (gt == 2) WS_GO(1, 2, 1); else if (dt == 2) WS_GO(1, 1, 2); else WS_GO(1, 1, 1);
+    } else {
+        if (gt == 2) WS_GO(2, 2, 1); else if (dt == 2) WS_GO(2, 1, 2); else WS_GO(2, 1, 1);
+    }
+#undef WS_GO
+    return p2p_check_launch("p2p_wgrad_small");
+}
+
+extern "C" int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
+                               const p2p_tensor* lo, float* dw, void* workspace, void* stream) {
+    P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && dw && workspace, "p2p_wgrad_small: null pointer");
+    P2P_REQUIRE(stride == 1 || stride == 2, "p2p_wgrad_small: stride must be 1 or 2");
+    const int nblocks = p2p_wgrad_small_blocks(dtype, stride, N, LH, LW, Cg, Cd, hi->ld, lo->ld);
+    P2P_REQUIRE(nblocks > 0, "p2p_wgrad_small: shape not supported (query p2p_wgrad_small_blocks)");
+    P2P_REQUIRE(((uintptr_t)hi->ptr % 16) == 0 && ((uintptr_t)lo->ptr % 16) == 0, "p2p_wgrad_small: views must be 16-byte aligned");
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    WsArgs a;
+    a.hi = (const char*)hi->ptr; a.hi_img = hi->img_stride; a.hi_row = hi->row_stride; a.hi_ld = hi->ld;
+    a.lo = (const char*)lo->ptr; a.lo_img = lo->img_stride; a.lo_row = lo->row_stride; a.lo_ld = lo->ld;
+    a.part = (float*)workspace;
+    a.N = N; a.LH = LH; a.LW = LW; a.Cg = Cg; a.Cd = Cd;
+    int TH = 512 / LW;
+    if (TH > 8) TH = 8;
+    if (TH > LH) TH = LH;
+    a.TH = TH;
+    a.strips_per_img = LH / TH;
+    a.nstrips = N * a.strips_per_img;
+    const size_t hi_bytes = (size_t)(stride * TH + 3) * (stride * LW + 3) * hi->ld * esz;
+    const size_t lo_bytes = (size_t)TH * LW * lo->ld * esz;
+    const size_t shm = ((hi_bytes + 15) & ~(size_t)15) + 256 + lo_bytes + 512;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    P2P_DISPATCH_DTYPE(dtype, rc = ws_launch<T>(a, stride, nblocks, shm, st));
+    if (rc) return rc;
+    const int n = 16 * Cg * Cd;
+    ws_slab_sum_kernel<<<dim3((n + 63) / 64), 256, 0, st>>>((const float*)workspace, nblocks, n, dw);
+    return p2p_check_launch("p2p_wgrad_small reduce");
+}

@@ -449,6 +449,9 @@ class Pix2PixEngine:
             best = max(best, self._msplit(B, lh, cg, cd) * 16 * cg * cd * 4)
         for cg, cd, lh in ((2 * self.in_ch, 64, S // 2), (64, 1, S // 2)):
             best = max(best, self._msplit(2 * B, lh, cg, cd) * 16 * cg * cd * 4)
+        # LDS-resident edge form: up to 512 partial slabs of 16*Cg*Cd floats
+        for cg, cd in ((self.in_ch, 64), (2 * self.in_ch, 64), (64, 1), (32 + self.in_ch, min(self.out_ch, 64))):
+            best = max(best, 512 * 16 * cg * cd * 4)
         return best
 
     # ------------------------------------------------------------------ kernel wrappers
@@ -515,6 +518,13 @@ class Pix2PixEngine:
             L.call("p2p_conv_direct", L.OP_W, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo),
                    NULL, NULL, dw, dbias if dbias is not None else NULL, _stream())
             return
+        if not lw.main:
+            nb = L.lib().p2p_wgrad_small_blocks(self.dtype, stride, N, lh, lh, cg, cd, hi.ld, lo.ld)
+            if nb > 0 and nb * 16 * cg * cd <= P["wws"].numel():
+                L.call("p2p_wgrad_small", self.dtype, stride, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), dw, _p(P["wws"]), _stream())
+                if dbias is not None:
+                    L.call("p2p_view_colsum", self.dtype, N, lh, lh, cd, C.byref(lo), dbias, _stream())
+                return
         ms = self._msplit(N, lh, cg, cd)
         ws = _p(P["wws"]) if ms > 1 else NULL
         if lw.main and stride == 2:

@@ -348,3 +348,21 @@ def test_igemm_fused_instance_norm_statistics(dtype, op, n, lh, cg, cd):
     want = torch.relu(rg.instance_norm(torch.tensor(x), torch.tensor(gamma, dtype=F64), torch.tensor(beta, dtype=F64))).numpy()
     assert U.rel_err(U.halo_to_np(y), want) < OUT_TOL[dtype]
     np.testing.assert_allclose(stats[..., 0].cpu().numpy(), x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5 * np.abs(x).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lh,cg,cd,stride", [(3, 32, 4, 64, 2), (2, 32, 8, 64, 2), (2, 64, 36, 4, 1), (3, 32, 64, 1, 1),
+                                                (2, 16, 1, 64, 2), (20, 64, 33, 8, 1)])
+def test_wgrad_small_lds_resident(dtype, n, lh, cg, cd, stride):
+    """Edge-layer weight gradients through the LDS-resident kernel (all 16 taps out of one staged strip)."""
+    rng = np.random.default_rng(18)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, stride, dtype)
+    _, _, w_ref = oracle_ops(hi, lo, w, stride)
+    hi_b, lo_b = _pad_view_input(hi, E.pad8(cg), dtype), _pad_view_input(lo, E.pad8(cd), dtype)
+    nb = L.lib().p2p_wgrad_small_blocks(dtype, stride, n, lh, lh, cg, cd, E.pad8(cg), E.pad8(cd))
+    assert nb > 0
+    ws = torch.full((nb * 16 * cg * cd,), float("nan"), dtype=torch.float32, device=U.DEV)
+    dw = torch.full((16 * cg * cd,), float("nan"), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_wgrad_small", dtype, stride, n, lh, lh, cg, cd, C.byref(hi_b.view()), C.byref(lo_b.view()), U.ptr(dw), U.ptr(ws),
+           U.stream())
+    assert U.rel_err(dw.cpu().numpy().reshape(4, 4, cg, cd), w_ref) < 2e-5
