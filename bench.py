@@ -194,6 +194,14 @@ def main():
             prof, records = kernel_profile(eng, run_step_eager)
             result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype, MFMA_PEAK[args.dtype])
+            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; reduced
+            # by tools/pmc_traffic.py from separate --pmc runs of this same command and committed under profiles/)
+            pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}_{args.dtype}.json")
+            if os.path.exists(pmc):
+                k = json.load(open(pmc))["kernels"].get(result["roofline"]["kernel"])
+                if k and k.get("hbm_bytes_per_launch"):
+                    result["roofline"]["traffic"] = round(k["hbm_bytes_per_launch"])
+                    result["roofline"]["traffic_unit"] = "bytes/launch (PMC)"
             if args.detail:
                 FL.write_detail(records, args.detail, n_steps=3)
         if not args.no_cpu_baseline:

@@ -158,6 +158,17 @@ __global__ void pack_multi_kernel(int N, int H, int W, int C, const void* __rest
         int x = (int)(p % W);
         int y = (int)((p / W) % H);
         int n = (int)(p / ((long long)W * H));
+        if (C == 4 && !src_is_int) {      // RGBA pixel: one 16-byte read, one 4-channel vector store per view
+            typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+            f32x4 v = *(const f32x4*)((const float*)src + p * 4);
+            vec4_t q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = from_f32<T>(v[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < dst.n) *(vec4_t*)((T*)dst.v[k].ptr + dst.v[k].off(n, y, x)) = q;
+            continue;
+        }
         for (int c = 0; c < C; ++c) {
             float v = src_is_int ? (float)((const int*)src)[p * C + c] : ((const float*)src)[p * C + c];
             T q = from_f32<T>(v);
@@ -174,6 +185,12 @@ extern "C" int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const
     PackDst d;
     d.n = ndst;
     for (int k = 0; k < 4; ++k) d.v[k] = make_view(&dsts[k < ndst ? k : 0]);
+    if (C == 4 && !src_is_int) {      // the vector path needs 4-channel-aligned views
+        const int esz = dtype == P2P_BF16 ? 2 : 4;
+        for (int k = 0; k < ndst; ++k)
+            P2P_REQUIRE(((uintptr_t)dsts[k].ptr % (4 * esz)) == 0 && (dsts[k].ld % 4) == 0 && ((uintptr_t)src % 16) == 0,
+                        "p2p_pack_input_multi: RGBA views must be aligned to 4 channels");
+    }
     long long total = (long long)N * H * W;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;

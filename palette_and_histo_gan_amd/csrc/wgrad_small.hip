@@ -35,8 +35,13 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int TW = a.LW, TH = a.TH;
     const int RH = S * TH + 3, RW = S * TW + 3;                 // hi strip incl. halo, pixels
-    const int hpB = a.hi_ld * ESZ, lpB = a.lo_ld * ESZ;         // pixel bytes (multiples of 16)
-    const int hrowB = RW * hpB;                                  // bytes per strip row in LDS (= contiguous HBM run)
+    const int hgB = a.hi_ld * ESZ, lgB = a.lo_ld * ESZ;         // pixel bytes in HBM (multiples of 16)
+    // channel windows of this workgroup (blockIdx.y: d window, blockIdx.z: g window).  A pixel wider than the window is
+    // staged as its window only (LDS pixel stride = window bytes); a narrower pixel is staged whole and over-read.
+    const int g0 = blockIdx.z * 32 * GT, d0 = blockIdx.y * 32 * DT;
+    const int hpB = hgB > 64 * GT * (ESZ / 2) ? 64 * GT * (ESZ / 2) : hgB;     // LDS bytes per hi pixel
+    const int lpB = lgB > 64 * DT * (ESZ / 2) ? 64 * DT * (ESZ / 2) : lgB;     // LDS bytes per lo pixel
+    const int hrowB = RW * hpB;                                  // bytes per strip row in LDS
     const int hi_bytes = RH * hrowB;
     const int lrowB = TW * lpB;
     char* hiL = smem;
@@ -56,21 +61,25 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
         const int n = strip / a.strips_per_img, y0 = (strip % a.strips_per_img) * TH;
         __syncthreads();      // previous strip fully consumed
         // ---- stage the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
-        const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row;
+        const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row, hcpp = hpB >> 4;
         for (int cI = wave * 64; cI < hchunks; cI += 512) {
             int ci = cI + lane;
             if (ci < hchunks) {
                 int rr = ci / hchunks_row, cc = ci - rr * hchunks_row;
-                const char* src = a.hi + ((long long)n * a.hi_img + (long long)(S * y0 - 1 + rr) * a.hi_row - 1) * hpB + cc * 16;
+                int px = cc / hcpp, ch = cc - px * hcpp;            // pixel of the strip row, 16-byte chunk inside its window
+                const char* src = a.hi + ((long long)n * a.hi_img + (long long)(S * y0 - 1 + rr) * a.hi_row - 1 + px) * hgB +
+                                  (hpB == hgB ? 0 : g0 * ESZ) + ch * 16;
                 glds16s(src, hiL + cI * 16);       // wave-uniform base + lane*16
             }
         }
-        const int lchunks_row = lrowB >> 4, lchunks = TH * lchunks_row;
+        const int lchunks_row = lrowB >> 4, lchunks = TH * lchunks_row, lcpp = lpB >> 4;
         for (int cI = wave * 64; cI < lchunks; cI += 512) {
             int ci = cI + lane;
             if (ci < lchunks) {
                 int rr = ci / lchunks_row, cc = ci - rr * lchunks_row;
-                const char* src = a.lo + ((long long)n * a.lo_img + (long long)(y0 + rr) * a.lo_row) * lpB + cc * 16;
+                int px = cc / lcpp, ch = cc - px * lcpp;
+                const char* src = a.lo + ((long long)n * a.lo_img + (long long)(y0 + rr) * a.lo_row + px) * lgB +
+                                  (lpB == lgB ? 0 : d0 * ESZ) + ch * 16;
                 glds16s(src, loL + cI * 16);
             }
         }
@@ -142,6 +151,7 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
     }
     // ---- partial store: D[row = g][col = d] ------------------------------------------------------------------------
     float* outp = a.part + (long long)blockIdx.x * 16 * a.Cg * a.Cd;
+    const int gwin = (hpB == hgB) ? 0 : g0, dwin = (lpB == lgB) ? 0 : d0;      // whole-pixel staging covers window 0 only
     const int h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -150,11 +160,11 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
         for (int i = 0; i < GT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                int g = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                int g = gwin + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (g >= a.Cg) continue;
 #pragma unroll
                 for (int j = 0; j < DT; ++j) {
-                    int d = j * 32 + (lane & 31);
+                    int d = dwin + j * 32 + (lane & 31);
                     if (d < a.Cd) outp[((long long)tap * a.Cg + g) * a.Cd + d] = acc[t][i][j][e];
                 }
             }
@@ -173,26 +183,56 @@ __global__ void ws_slab_sum_kernel(const float* __restrict__ part, int nslabs, i
     if (sg == 0 && o < n) out[o] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// Applicability / workspace of the LDS-resident form.  Returns the number of partial slabs (workgroups) or 0.
-extern "C" int p2p_wgrad_small_blocks(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
+// Tiling of the LDS-resident form: 32x32 MFMA tiles per workgroup (GT x DT <= 4), channel windows, strip height.
+struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks; size_t shm; };
+
+static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
+    WsPlan p = {0, 0, 0, 0, 0, 0, 0, 0};
     const int esz = dtype == P2P_BF16 ? 2 : 4;
-    if (Cg > 64 || Cd > 64 || ((Cg + 31) / 32) * ((Cd + 31) / 32) > 2) return 0;
-    if ((LW & (LW - 1)) || LW < 16 || LW > 64) return 0;
-    if ((hi_ld * esz) % 16 || (lo_ld * esz) % 16) return 0;
+    if ((LW & (LW - 1)) || LW < 16 || LW > 64) return p;
+    if ((hi_ld * esz) % 16 || (lo_ld * esz) % 16) return p;
+    const int gt_all = (Cg + 31) / 32, dt_all = (Cd + 31) / 32;
+    // windows: at most 2 tiles along g, then as many along d as keep GT*DT <= 4
+    p.GT = gt_all >= 2 ? 2 : 1;
+    p.DT = dt_all >= 4 ? (p.GT == 1 ? 4 : 2) : (dt_all >= 2 ? 2 : 1);
+    if (p.GT * p.DT > 4) p.DT = 4 / p.GT;
+    p.gwins = (gt_all + p.GT - 1) / p.GT;
+    p.dwins = (dt_all + p.DT - 1) / p.DT;
+    if (p.gwins * p.dwins > 8) return p;                 // beyond that the general kernel (wgemm.hip) re-reads less
     int TH = 512 / LW;
     if (TH > 8) TH = 8;
     if (TH > LH) TH = LH;
-    if (LH % TH) return 0;
-    const long long hi_bytes = (long long)(stride * TH + 3) * (stride * LW + 3) * hi_ld * esz;
-    const long long lo_bytes = (long long)TH * LW * lo_ld * esz;
-    if (hi_bytes + lo_bytes + 1024 > 150 * 1024) return 0;
+    for (;; TH >>= 1) {
+        if (TH < 1 || LH % TH) return p;
+        const size_t hpB = (size_t)hi_ld * esz > (size_t)64 * p.GT * (esz / 2) ? (size_t)64 * p.GT * (esz / 2) : (size_t)hi_ld * esz;
+        const size_t lpB = (size_t)lo_ld * esz > (size_t)64 * p.DT * (esz / 2) ? (size_t)64 * p.DT * (esz / 2) : (size_t)lo_ld * esz;
+        const size_t hi_bytes = (size_t)(stride * TH + 3) * (stride * LW + 3) * hpB;
+        const size_t lo_bytes = (size_t)TH * LW * lpB;
+        p.shm = ((hi_bytes + 15) & ~(size_t)15) + 256 + lo_bytes + 512;
+        if (p.shm <= 150 * 1024) break;
+        if (TH == 1) return p;
+    }
+    p.TH = TH;
     long long strips = (long long)N * (LH / TH);
-    return (int)(strips < 512 ? strips : 512);
+    long long want = 512 / (p.gwins * p.dwins);
+    const long long slab_bytes = 16LL * Cg * Cd * 4;
+    const long long cap = (64LL << 20) / slab_bytes;         // keep the partial slabs within 64 MB
+    if (want > cap) want = cap;
+    if (want < 32) want = 32;
+    p.blocks = (int)(strips < want ? strips : want);
+    p.ok = 1;
+    return p;
+}
+
+// Applicability / workspace of the LDS-resident form.  Returns the number of partial slabs (workgroups along x) or 0.
+extern "C" int p2p_wgrad_small_blocks(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
+    WsPlan p = ws_plan(dtype, stride, N, LH, LW, Cg, Cd, hi_ld, lo_ld);
+    return p.ok ? p.blocks : 0;
 }
 
 template <typename T>
-static int ws_launch(WsArgs& a, int stride, int nblocks, size_t shm, hipStream_t st) {
-    const int gt = (a.Cg + 31) / 32, dt = (a.Cd + 31) / 32;
+static int ws_launch(WsArgs& a, int stride, const WsPlan& p, hipStream_t st) {
+    dim3 grid(p.blocks, p.dwins, p.gwins);
 #define WS_GO(S_, G_, D_)                                                                                              \
     do {                                                                                                               \
         static bool done = false;                                                                                      \
@@ -200,13 +240,18 @@ static int ws_launch(WsArgs& a, int stride, int nblocks, size_t shm, hipStream_t
             (void)hipFuncSetAttribute((const void*)wgrad_small_kernel<T, S_, G_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             done = true;                                                                                               \
         }                                                                                                              \
-        wgrad_small_kernel<T, S_, G_, D_><<<dim3(nblocks), dim3(512), shm, st>>>(a);                                   \
+        wgrad_small_kernel<T, S_, G_, D_><<<grid, dim3(512), p.shm, st>>>(a);                                          \
     } while (0)
-    if (stride == 1) {
-        if (gt == 2) WS_GO(1, 2, 1); else if (dt == 2) WS_GO(1, 1, 2); else WS_GO(1, 1, 1);
-    } else {
-        if (gt == 2) WS_GO(2, 2, 1); else if (dt == 2) WS_GO(2, 1, 2); else WS_GO(2, 1, 1);
-    }
+#define WS_SEL(S_)                                                                                                     \
+    do {                                                                                                               \
+        if (p.GT == 1 && p.DT == 1) WS_GO(S_, 1, 1);                                                                   \
+        else if (p.GT == 1 && p.DT == 2) WS_GO(S_, 1, 2);                                                              \
+        else if (p.GT == 1 && p.DT == 4) WS_GO(S_, 1, 4);                                                              \
+        else if (p.GT == 2 && p.DT == 1) WS_GO(S_, 2, 1);                                                              \
+        else WS_GO(S_, 2, 2);                                                                                          \
+    } while (0)
+    if (stride == 1) WS_SEL(1); else WS_SEL(2);
+#undef WS_SEL
 #undef WS_GO
     return p2p_check_launch("p2p_wgrad_small");
 }
@@ -215,8 +260,9 @@ extern "C" int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int
                                const p2p_tensor* lo, float* dw, void* workspace, void* stream) {
     P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && dw && workspace, "p2p_wgrad_small: null pointer");
     P2P_REQUIRE(stride == 1 || stride == 2, "p2p_wgrad_small: stride must be 1 or 2");
-    const int nblocks = p2p_wgrad_small_blocks(dtype, stride, N, LH, LW, Cg, Cd, hi->ld, lo->ld);
-    P2P_REQUIRE(nblocks > 0, "p2p_wgrad_small: shape not supported (query p2p_wgrad_small_blocks)");
+    const WsPlan plan = ws_plan(dtype, stride, N, LH, LW, Cg, Cd, hi->ld, lo->ld);
+    P2P_REQUIRE(plan.ok, "p2p_wgrad_small: shape not supported (query p2p_wgrad_small_blocks)");
+    const int nblocks = plan.blocks;
     P2P_REQUIRE(((uintptr_t)hi->ptr % 16) == 0 && ((uintptr_t)lo->ptr % 16) == 0, "p2p_wgrad_small: views must be 16-byte aligned");
     const int esz = dtype == P2P_BF16 ? 2 : 4;
     WsArgs a;
@@ -224,18 +270,13 @@ extern "C" int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int
     a.lo = (const char*)lo->ptr; a.lo_img = lo->img_stride; a.lo_row = lo->row_stride; a.lo_ld = lo->ld;
     a.part = (float*)workspace;
     a.N = N; a.LH = LH; a.LW = LW; a.Cg = Cg; a.Cd = Cd;
-    int TH = 512 / LW;
-    if (TH > 8) TH = 8;
-    if (TH > LH) TH = LH;
-    a.TH = TH;
-    a.strips_per_img = LH / TH;
+    (void)esz;
+    a.TH = plan.TH;
+    a.strips_per_img = LH / plan.TH;
     a.nstrips = N * a.strips_per_img;
-    const size_t hi_bytes = (size_t)(stride * TH + 3) * (stride * LW + 3) * hi->ld * esz;
-    const size_t lo_bytes = (size_t)TH * LW * lo->ld * esz;
-    const size_t shm = ((hi_bytes + 15) & ~(size_t)15) + 256 + lo_bytes + 512;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    P2P_DISPATCH_DTYPE(dtype, rc = ws_launch<T>(a, stride, nblocks, shm, st));
+    P2P_DISPATCH_DTYPE(dtype, rc = ws_launch<T>(a, stride, plan, st));
     if (rc) return rc;
     const int n = 16 * Cg * Cd;
     ws_slab_sum_kernel<<<dim3((n + 63) / 64), 256, 0, st>>>((const float*)workspace, nblocks, n, dw);

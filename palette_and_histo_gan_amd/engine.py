@@ -449,10 +449,8 @@ class Pix2PixEngine:
             best = max(best, self._msplit(B, lh, cg, cd) * 16 * cg * cd * 4)
         for cg, cd, lh in ((2 * self.in_ch, 64, S // 2), (64, 1, S // 2)):
             best = max(best, self._msplit(2 * B, lh, cg, cd) * 16 * cg * cd * 4)
-        # LDS-resident edge form: up to 512 partial slabs of 16*Cg*Cd floats
-        for cg, cd in ((self.in_ch, 64), (2 * self.in_ch, 64), (64, 1), (32 + self.in_ch, min(self.out_ch, 64))):
-            best = max(best, 512 * 16 * cg * cd * 4)
-        return best
+        # LDS-resident form: partial slabs of 16*Cg*Cd floats, at most 64 MB (wgrad_small.hip ws_plan)
+        return max(best, (64 << 20) + 16)
 
     # ------------------------------------------------------------------ kernel wrappers
     def _conv(self, P, op, sid, name, N, lh, in_view, out_view, stride=2, ncols=None, bias=None, act=L.ACT_NONE,
@@ -518,7 +516,7 @@ class Pix2PixEngine:
             L.call("p2p_conv_direct", L.OP_W, stride, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo),
                    NULL, NULL, dw, dbias if dbias is not None else NULL, _stream())
             return
-        if not lw.main:
+        if lh >= 16:      # strips of >= 16 pixels per row: contract all 16 taps out of one LDS-resident strip
             nb = L.lib().p2p_wgrad_small_blocks(self.dtype, stride, N, lh, lh, cg, cd, hi.ld, lo.ld)
             if nb > 0 and nb * 16 * cg * cd <= P["wws"].numel():
                 L.call("p2p_wgrad_small", self.dtype, stride, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), dw, _p(P["wws"]), _stream())

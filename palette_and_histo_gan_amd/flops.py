@@ -69,7 +69,25 @@ def roofline_for_dominant(prof, records, B, S, dtype, peak_tflops):
     achieved = fl / (ms * 1e-3) / 1e12
     return {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tflops, "unit": "TFLOP/s",
             "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": n,
-            "avg_launch_ms": round(ms / n, 5), "flops_per_launch_avg": fl / n}
+            "avg_launch_ms": round(ms / n, 5), "flops_per_launch_avg": fl / n,
+            "algorithmic_bytes_per_launch_avg": _dominant_bytes(dominant, records, dtype) / n}
+
+
+def _dominant_bytes(dominant, records, dtype):
+    """Algorithmic HBM bytes of the conv launches: input view + weights + output, each touched once."""
+    esz = 2 if dtype == "bf16" else 4
+    tot = 0.0
+    for name, args, a, b in records:
+        if name != dominant:
+            continue
+        if name == "p2p_igemm":
+            _, _, n, lh, lw, cg, cd = args[:7]
+        elif name == "p2p_wgemm":
+            _, n, lh, lw, cg, cd = args[:6]
+        else:
+            continue
+        tot += (n * 4 * lh * lw * cg + n * lh * lw * cd + 16 * cg * cd) * esz
+    return tot
 
 
 def write_detail(records, path, n_steps):
