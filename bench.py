@@ -31,6 +31,7 @@ CONFIGS = {
     "c1": ("baseline", 4, 64, 100.0, None, None),
     "c2": ("baseline", 256, 64, 100.0, None, None),
     "c3": ("histogram", 256, 64, 30.0, 1.0, 24),
+    "c4": ("indexed", 128, 64, 0.01, None, 24),          # lambda = lambda_segmentation (experiments.ipynb:228)
     "c5": ("histogram", 256, 128, 30.0, 1.0, 24),
 }
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # TFLOP/s dense, MI355X_MICROARCH.md chip-level parameters
@@ -140,15 +141,23 @@ def main():
     if args.batch:
         B = args.batch
     dtype = L.BF16 if args.dtype == "bf16" else L.F32
-    eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype, device=device, seed=47, use_mfma=not args.no_mfma)
-    src, tgt = synthetic_batch(rank, B, S, palette)
+    indexed = model == "indexed"
+    if indexed:
+        from oracle import reference_graph as rg
+        eng = E.Pix2PixEngine(1, 256, "softmax", S, dtype, device=device, seed=47, use_mfma=not args.no_mfma)
+        src, tgt, _pal = rg.synthetic_indexed_batch(np.random.default_rng([47, rank]), B, S, palette)
+    else:
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype, device=device, seed=47, use_mfma=not args.no_mfma)
+        src, tgt = synthetic_batch(rank, B, S, palette)
     src_d = torch.as_tensor(src).to(device)
     tgt_d = torch.as_tensor(tgt).to(device)
 
     def run_step_eager():
+        if indexed:
+            return eng.train_step_indexed(src_d, tgt_d, lam_l1, global_batch=B * world, dp=comm)
         return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, dp=comm)
 
-    use_graph = world == 1 and args.graph
+    use_graph = world == 1 and args.graph and not indexed
     if use_graph:
         graphed = eng.graphed_rgba_step(B, lam_l1, lam_hist, global_batch=B)
 
@@ -179,15 +188,16 @@ def main():
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.config}: {model} Pix2Pix train step, per-GPU batch {B}, {S}x{S} RGBA sprites, "
-                               f"lambda_l1={lam_l1}" + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
+        "config": {"workload": f"{args.config}: {model} Pix2Pix train step, per-GPU batch {B}, {S}x{S} "
+                               + ("palette-index sprites (1 -> 256-way softmax), " f"lambda_seg={lam_l1}" if indexed else
+                                  "RGBA sprites, " f"lambda_l1={lam_l1}") + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
                    "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if use_graph else "eager"},
         "losses": [round(float(x), 5) for x in losses.cpu().numpy()],
     }
 
     if rank == 0:
-        flops_img = FL.train_step_flops_per_image(S, 4, 4)
+        flops_img = FL.train_step_flops_per_image(S, 1, 256, indexed=True) if indexed else FL.train_step_flops_per_image(S, 4, 4)
         result["conv_tflops"] = round(flops_img * value / 1e12, 2)
         result["conv_mfma_frac_of_peak"] = round(flops_img * value / 1e12 / (MFMA_PEAK[args.dtype] * world), 4)
         if not args.no_profile:
@@ -205,7 +215,7 @@ def main():
             if args.detail:
                 FL.write_detail(records, args.detail, n_steps=3)
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(model, S, lam_l1, lam_hist)
+            result["cpu_baseline"] = cpu_baseline("baseline" if indexed else model, S, 100.0 if indexed else lam_l1, lam_hist)
         print(json.dumps(result), flush=True)
     if comm is not None:
         comm.barrier()

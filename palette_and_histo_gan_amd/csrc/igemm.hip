@@ -19,6 +19,7 @@
 // GEN = true : any multiple of 16 bytes per tap (edge layers: 8-channel images, the 36(+4)-channel concat, the
 //              33(+7)-channel indexed concat), plus bias / LeakyReLU / column mask in the epilogue.
 #include "p2p_common.hpp"
+#include <stdlib.h>
 
 struct IgemmArgs {
     const char* in; long long in_img; int in_row; int in_ld;      // gathered input view (element strides)
@@ -56,7 +57,7 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T, int WM, int WN, int TM, int TN, bool GEN, bool VEPI>
+template <typename T, int WM, int WN, int TM, int TN, bool GEN, bool VEPI, int NST>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -162,12 +163,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 
     typedef typename Frag<T>::type frag_t;
 
+    // NST = 2: one K-block of prefetch, vmcnt(0) + barrier per K-block (two workgroups per CU hide each other's waits).
+    // NST = 3: ring of three LDS stages, two K-blocks of loads in flight across the barrier: a counted s_waitcnt leaves
+    //          the younger stage's LDS-DMA outstanding (cdna_hip_programming.md "Pipelining across barriers") -- for
+    //          launches that put a single workgroup on each CU.
+    constexpr int NL = NA + NB;                   // LDS-DMA instructions per thread per stage
     stage(0, smem);
+    if (NST == 3 && nkb > 1) stage(1, smem + STAGE);
     for (int kb = 0; kb < nkb; ++kb) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        char* cur = smem + (kb & 1) * STAGE;
-        if (kb + 1 < nkb) stage(kb + 1, smem + ((kb + 1) & 1) * STAGE);
+        if (NST == 3) {
+            if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        char* cur = smem + (NST == 3 ? (kb % 3) : (kb & 1)) * STAGE;
+        if (NST == 3) { if (kb + 2 < nkb) stage(kb + 2, smem + ((kb + 2) % 3) * STAGE); }
+        else if (kb + 1 < nkb) stage(kb + 1, smem + ((kb + 1) & 1) * STAGE);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             frag_t af[TM], bf[TN];
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     if constexpr (VEPI) {
         // stage the tile through LDS as [pixel][channel] in the OUTPUT type, then store whole 16-byte chunks of
         // each pixel's channel run (coalesced rows instead of 2-byte scatter).
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();      // every wave is done reading the operand tiles
         auto run = [&](auto tag) {
             typedef decltype(tag) TO;
@@ -315,22 +331,42 @@ static int ilog2_exact(long long v) {
     return (1LL << l) == v ? l : -1;
 }
 
+static int igemm_stage_override() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("P2P_IGEMM_STAGES"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <typename T, int WM, int WN, int TM, int TN, bool GEN>
 static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int ctiles = (a.ncols + 31) / 32 * 32;
     dim3 grid((a.M + BM - 1) / BM, (ctiles + BN - 1) / BN, gz);
-    size_t stage = 2 * (size_t)(BM + BN) * 128;
+    // three LDS stages when the launch cannot put two workgroups on every CU anyway (<= 320 workgroups) and the
+    // K loop is long enough to fill the ring
+    const long long nblk = (long long)grid.x * grid.y * grid.z;
+    const int nkb_host = (a.taps_per * a.C * (int)sizeof(T)) >> 7;
+    int nst = (nblk <= 320 && nkb_host >= 4) ? 3 : 2;
+    if (igemm_stage_override() == 2 || igemm_stage_override() == 3) nst = igemm_stage_override();
+    if (3 * (size_t)(BM + BN) * 128 > 150 * 1024) nst = 2;
+    size_t stage = (size_t)nst * (BM + BN) * 128;
     size_t epi = (size_t)BM * (BN * 4 + 16) + 4096;    // f32 staging of the epilogue is the larger case (+ stats scratch)
     size_t shm = vepi ? (stage > epi ? stage : epi) : stage;
-    static bool attr_done[2] = {false, false};      // per template instantiation: allow > 64 KB of dynamic LDS
-    if (!attr_done[vepi]) {
-        if (vepi) (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        else (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done[vepi] = true;
+    static bool attr_done = false;      // per template instantiation: allow > 64 KB of dynamic LDS
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, WM, WN, TM, TN, GEN, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
     }
-    if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true><<<grid, dim3(256), shm, st>>>(a);
-    else igemm_kernel<T, WM, WN, TM, TN, GEN, false><<<grid, dim3(256), shm, st>>>(a);
+    if (nst == 3) {
+        if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true, 3><<<grid, dim3(256), shm, st>>>(a);
+        else igemm_kernel<T, WM, WN, TM, TN, GEN, false, 3><<<grid, dim3(256), shm, st>>>(a);
+    } else {
+        if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true, 2><<<grid, dim3(256), shm, st>>>(a);
+        else igemm_kernel<T, WM, WN, TM, TN, GEN, false, 2><<<grid, dim3(256), shm, st>>>(a);
+    }
 }
 
 template <typename T, bool GEN>

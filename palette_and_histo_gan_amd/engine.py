@@ -9,6 +9,7 @@ tensors are only device-memory holders here; every arithmetic op on the path is 
 from collections import OrderedDict
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -250,6 +251,7 @@ class Pix2PixEngine:
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
+        self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self.refresh_weight_copies()
 
     # ------------------------------------------------------------------ parameters
@@ -402,7 +404,7 @@ class Pix2PixEngine:
         bn = 128 if ncols % 128 == 0 else (64 if ncols % 64 == 0 else 32)
         blocks = ((B * lh * lh + 127) // 128) * (ncols // bn) * (1 if op == L.OP_G else 4)
         sk = 1
-        while blocks * sk < 256 and sk * 2 <= ntaps and ((ntaps // (sk * 2)) * cc * esz) % 128 == 0:
+        while blocks * sk < self.splitk_target and sk * 2 <= ntaps and ((ntaps // (sk * 2)) * cc * esz) % 128 == 0:
             sk *= 2
         return sk
 

@@ -138,3 +138,24 @@ def test_generate_is_forward_of_train_step():
     fake = eng.generate(src, masks=masks).cpu().numpy()
     ref = rg.unet_generator(Gp, torch.tensor(src, dtype=F64), [torch.tensor(m, dtype=F64) for m in masks], "tanh").numpy()
     assert np.abs(fake - ref).max() < 1e-4
+
+
+def test_train_step_128x128_sprites_f32():
+    """BASELINE.json config 5 geometry: IMG_SIZE = 128, the depth stays 6 so the bottleneck is 2x2 and down6 is live
+    (north_star discrepancies).  Histogram model, B = 1."""
+    B, S = 1, 128
+    rng, Gp, Dp, src, tgt, masks = setup_case(B, S, 25)
+    tm = [torch.tensor(m, dtype=F64) for m in masks]
+    ref = rg.train_step_rgba(Gp, Dp, torch.tensor(src, dtype=F64), torch.tensor(tgt, dtype=F64), tm, lambda_l1=30.0, lambda_hist=1.0)
+    eng = E.Pix2PixEngine(4, 4, "tanh", S, L.F32)
+    eng.set_params(to_np(Gp), to_np(Dp))
+    out = eng.train_step_rgba(src, tgt, 30.0, lambda_hist=1.0, masks=masks, apply_update=False).cpu().numpy()
+    g, d = ref["g_loss"], ref["d_loss"]
+    want = np.array([g[0], g[1], g[2], g[3], d[0], d[1], d[2]])
+    for i in range(7):
+        assert abs(out[i] - want[i]) <= 1e-4 * abs(want[i]), (i, out[i], want[i])
+    wg = grad_report(eng.G.export(eng.G.grads), ref["g_grads"])
+    wd = grad_report(eng.D.export(eng.D.grads), ref["d_grads"])
+    print("worst G", wg, "worst D", wd)
+    assert float(np.abs(ref["g_grads"]["down6.kernel"].numpy()).max()) > 0.0        # live at S = 128
+    assert wg[1][1] < 2e-3 and wd[1][1] < 1e-4
