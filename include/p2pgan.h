@@ -96,6 +96,15 @@ int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin
                    const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
                    int act, float alpha, void* stream);
 
+/* LDS-resident form of p2p_igemm_edge for the layers whose whole weight tensor fits in LDS (<= 96 KB as
+ * [16][ncols up to 128][cin_pad]) and whose rows are 16..64 pixels wide: weights stay in LDS for the life of the
+ * workgroup, every input strip is staged once, all taps are contracted out of LDS.  Same arguments and semantics as
+ * p2p_igemm_edge; p2p_conv_edge_ok tells whether the shape is supported. */
+int p2p_conv_edge_ok(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols);
+int p2p_conv_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                  const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
+                  int act, float alpha, void* stream);
+
 /* MFMA weight gradient of a stride-2 block: dw[16][Cg][Cd] (f32) = sum over pixels.  The pixel sum is
  * split over `msplit` workgroups per tile; partial slabs go to `workspace`
  * (p2p_wgemm_workspace_bytes) and are reduced deterministically. */

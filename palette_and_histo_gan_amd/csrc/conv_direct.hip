@@ -112,23 +112,35 @@ __global__ void conv_direct_W(int stride, int N, int LH, int LW, int Cg, int Cd,
     atomicAdd(dw + idx, acc);
 }
 
-// dbias[d] += sum over pixel chunk of lo[m][d]
+// dbias[d] += sum over a chunk of pixels of lo[m][d]: threads = (pixel lane) x (channel), coalesced over channels,
+// pixel lanes folded through LDS, one atomic per channel per workgroup
 template <typename T>
 __global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk) {
-    __shared__ float red[16];
-    long long M = (long long)N * LH * LW;
-    long long m0 = (long long)blockIdx.x * chunk;
-    long long m1 = m0 + chunk < M ? m0 + chunk : M;
-    for (int d = 0; d < Cd; ++d) {
+    __shared__ float red[256];
+    const int M = N * LH * LW;                     // < 2^31 pixels
+    const int m0 = blockIdx.x * chunk;
+    const int m1 = m0 + chunk < M ? m0 + chunk : M;
+    const int cpt = Cd < 256 ? Cd : 256;          // channels handled at once
+    const int PL = 256 / cpt;                      // pixel lanes
+    const int c = threadIdx.x % cpt, pl = threadIdx.x / cpt;
+    for (int c0 = 0; c0 < Cd; c0 += cpt) {
         float acc = 0.f;
-        for (long long m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
-            int x = (int)(m % LW);
-            int y = (int)((m / LW) % LH);
-            int n = (int)(m / ((long long)LW * LH));
-            acc += to_f32(((const T*)lo.ptr)[lo.off(n, y, x) + d]);
+        if (pl < PL && c0 + c < Cd)
+            for (int m = m0 + pl; m < m1; m += PL) {
+                int x = m % LW;
+                int q = m / LW;
+                int y = q % LH;
+                int n = q / LH;
+                acc += to_f32(((const T*)lo.ptr)[lo.off(n, y, x) + c0 + c]);
+            }
+        __syncthreads();
+        red[threadIdx.x] = (pl < PL) ? acc : 0.f;
+        __syncthreads();
+        if (pl == 0 && c0 + c < Cd) {
+            float s2 = 0.f;
+            for (int i = 0; i < PL; ++i) s2 += red[i * cpt + c];
+            atomicAdd(out + c0 + c, s2);
         }
-        float s = block_sum(acc, red);
-        if (threadIdx.x == 0) atomicAdd(out + d, s);
     }
 }
 
@@ -139,7 +151,8 @@ extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
     if (e != hipSuccess) { p2p_set_error("p2p_view_colsum memset: %s", hipGetErrorString(e)); return (int)e; }
     long long M = (long long)N * H * W;
-    int chunk = 4096;
+    P2P_REQUIRE(M < (1LL << 31), "p2p_view_colsum: too many pixels");
+    int chunk = C >= 64 ? 256 : 2048;            // wide pixels: few pixel lanes per workgroup -> more workgroups
     P2P_DISPATCH_DTYPE(dtype, (view_colsum<T><<<dim3((unsigned)((M + chunk - 1) / chunk)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunk)));
     return p2p_check_launch("p2p_view_colsum");
 }

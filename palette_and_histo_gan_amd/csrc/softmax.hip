@@ -31,10 +31,17 @@ __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, i
         const T* zp = (const T*)z.ptr + z.off(n, y, x);
         float v[8];
         float mx = -INFINITY;
-        for (int k = 0; k < per; ++k) {
-            int c = lane * per + k;
-            v[k] = c < C ? to_f32(zp[c]) : -INFINITY;
-            mx = fmaxf(mx, v[k]);
+        if (C == 256) {       // 4 logits per lane: one 8-byte (bf16) / 16-byte (f32) load
+            typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+            vec4_t r = *(const vec4_t*)(zp + lane * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = to_f32((T)r[k]); mx = fmaxf(mx, v[k]); }
+        } else {
+            for (int k = 0; k < per; ++k) {
+                int c = lane * per + k;
+                v[k] = c < C ? to_f32(zp[c]) : -INFINITY;
+                mx = fmaxf(mx, v[k]);
+            }
         }
         mx = wave_max(mx);
         float s = 0.f;
@@ -67,9 +74,17 @@ __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, i
         }
         if (dz.ptr) {
             T* dp = (T*)dz.ptr + dz.off(n, y, x);
-            for (int k = 0; k < per; ++k) {
-                int c = lane * per + k;
-                if (c < C) dp[c] = from_f32<T>((v[k] - (c == t ? 1.f : 0.f)) * grad_scale);
+            if (C == 256) {
+                typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+                vec4_t r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = from_f32<T>((v[k] - (lane * 4 + k == t ? 1.f : 0.f)) * grad_scale);
+                *(vec4_t*)(dp + lane * 4) = r;
+            } else {
+                for (int k = 0; k < per; ++k) {
+                    int c = lane * per + k;
+                    if (c < C) dp[c] = from_f32<T>((v[k] - (c == t ? 1.f : 0.f)) * grad_scale);
+                }
             }
         }
         if (probs_out)
@@ -121,7 +136,10 @@ extern "C" int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, con
     else { d.ptr = nullptr; d.img = 0; d.row = 0; d.ld = 0; }
     long long M = (long long)N * H * W;
     long long blocks = (M + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 4096) blocks = 4096;
+    if (C == 256)
+        P2P_REQUIRE(z->ld % 4 == 0 && ((uintptr_t)z->ptr % 16) == 0 && (!dz || !dz->ptr || (dz->ld % 4 == 0 && ((uintptr_t)dz->ptr % 16) == 0)),
+                    "p2p_softmax_cce_argmax: 256-way views must be 4-channel aligned");
     P2P_DISPATCH_DTYPE(dtype, (softmax_cce_argmax_kernel<T><<<dim3((unsigned)blocks), 256, 0, st>>>(
                                   N, H, W, C, make_view(z), make_view(target), make_view(fake_idx), grad_scale, inv_count, d,
                                   probs_out, loss_out)));

@@ -68,7 +68,11 @@ class HaloBuf:
     def __init__(self, n, h, w, c, dtype, device):
         self.n, self.h, self.w, self.c, self.dtype = n, h, w, c, dtype
         self.hp, self.wp = h + 2 * HALO, w + 2 * HALO
-        self.t = torch.zeros((n, self.hp, self.wp, c), dtype=_torch_dtype(dtype), device=device)
+        # 512 bytes of zeroed tail slack: the edge-layer weight-gradient tiles read whole 64/128-byte rows from pixels
+        # that hold fewer channels, i.e. up to 112 bytes past the last halo pixel of the last image
+        numel = n * self.hp * self.wp * c
+        self._flat = torch.zeros(numel + 256, dtype=_torch_dtype(dtype), device=device)
+        self.t = self._flat[:numel].view(n, self.hp, self.wp, c)
         self.esz = self.t.element_size()
 
     def view(self, coff=0, n0=0):
@@ -251,6 +255,7 @@ class Pix2PixEngine:
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
+        self.use_conv_edge = os.environ.get("P2P_CONV_EDGE", "1") != "0"      # LDS-resident edge convolutions
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self.refresh_weight_copies()
 
@@ -481,7 +486,9 @@ class Pix2PixEngine:
                 cin_pad, nc, rows, w = lw.hi_pad, cd, up32(cd), _p(lw.wt)
             else:
                 cin_pad, nc, rows, w = lw.lo_pad, (ncols or cg), up32(cg), self._wn(sid, name)
-            L.call("p2p_igemm_edge", op, stride, self.dtype, N, lh, lh, cin_pad, nc, rows, C.byref(in_view),
+            entry = "p2p_conv_edge" if self.use_conv_edge and L.lib().p2p_conv_edge_ok(op, stride, self.dtype, N, lh, lh, cin_pad, nc) \
+                else "p2p_igemm_edge"
+            L.call(entry, op, stride, self.dtype, N, lh, lh, cin_pad, nc, rows, C.byref(in_view),
                    C.byref(out_view), w, bias if bias is not None else NULL, act, LEAKY_ALPHA, _stream())
             return (1, 1)
         # direct (non-MFMA) cross-check path

@@ -262,9 +262,17 @@ def _pad_view_input(x, cpad, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lh,cg,cd,stride", [(2, 32, 4, 64, 2), (3, 32, 8, 64, 2), (2, 64, 36, 4, 1), (2, 32, 64, 1, 1),
+                                                (2, 16, 1, 64, 2), (5, 16, 33, 8, 1)])
+def test_edge_layers_lds_resident(dtype, n, lh, cg, cd, stride):
+    """Same layers through p2p_conv_edge (weights + input strip resident in LDS)."""
+    test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_conv_edge")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,stride", [(2, 8, 4, 64, 2), (3, 8, 8, 64, 2), (2, 16, 36, 4, 1), (2, 8, 64, 1, 1),
                                                 (1, 4, 33, 256, 1), (2, 8, 1, 64, 2)])
-def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride):
+def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_igemm_edge"):
     """The edge layers (networks.py:46-48,57,75-78) through p2p_igemm_edge / p2p_wgemm_edge: padded channel
     counts, stride 1 and 2, bias + LeakyReLU epilogue, masked columns."""
     rng = np.random.default_rng(16)
@@ -281,7 +289,11 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride):
     # op G with bias + LeakyReLU into a channel slice of a wider haloed buffer
     out_g = E.HaloBuf(n, lh, lh, cd + 8, dtype, U.DEV)
     bias_d = U.dev(bias)
-    L.call("p2p_igemm_edge", L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd, E.up32(cd), C.byref(hi_b.view()),
+    e_g = entry
+    if entry == "p2p_conv_edge" and not L.lib().p2p_conv_edge_ok(L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd):
+        assert dtype == L.F32 and hi_pad >= 64       # only the f32 copy of a 64-channel layer exceeds the LDS weight budget
+        e_g = "p2p_igemm_edge"
+    L.call(e_g, L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd, E.up32(cd), C.byref(hi_b.view()),
            C.byref(out_g.view(coff=8)), U.ptr(wt), U.ptr(bias_d), L.ACT_LEAKY, 0.3, U.stream())
     want = g_ref + bias
     want = np.where(want > 0, want, 0.3 * want)
@@ -292,7 +304,11 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride):
     ncols = min(cg, 32)
     out_p = E.DenseBuf(n, stride * lh, stride * lh, hi_pad, U.tdt(dtype), U.DEV)
     out_p.t.zero_()
-    L.call("p2p_igemm_edge", L.OP_P, stride, dtype, n, lh, lh, lo_pad, ncols, E.up32(cg), C.byref(lo_b.view()),
+    e_p = entry
+    if entry == "p2p_conv_edge" and not L.lib().p2p_conv_edge_ok(L.OP_P, stride, dtype, n, lh, lh, lo_pad, ncols):
+        assert dtype == L.F32 and lo_pad >= 64
+        e_p = "p2p_igemm_edge"
+    L.call(e_p, L.OP_P, stride, dtype, n, lh, lh, lo_pad, ncols, E.up32(cg), C.byref(lo_b.view()),
            C.byref(out_p.view()), U.ptr(wn), None, L.ACT_NONE, 0.0, U.stream())
     gp = U.dense_to_np(out_p)
     assert U.rel_err(gp[..., :ncols], p_ref[..., :ncols]) < OUT_TOL[dtype] * max(1.0, np.abs(p_ref).max() / (np.abs(p_ref[..., :ncols]).max() + 1e-30))
