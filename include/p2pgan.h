@@ -105,6 +105,16 @@ int p2p_conv_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin_
                   const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
                   int act, float alpha, void* stream);
 
+/* Few-output form (ncols <= 4, 32 < cin_pad <= 64; op G stride 1 or op P stride 2): the generator's 36 -> 4 head, the
+ * discriminator's 64 -> 1 head and d(D first conv)/d(fake image) 64 -> 4 (networks.py:46,57,75-78).  Contracts the
+ * channels first (rows = 16 taps x outputs, no padding of the 1..4 outputs to a 32-row tile, every input pixel read
+ * once), then sums the 16 shifted taps out of LDS in a fixed order.  Same arguments and semantics as p2p_igemm_edge;
+ * p2p_conv_fewout_ok tells whether the shape is supported. */
+int p2p_conv_fewout_ok(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols);
+int p2p_conv_fewout(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                    const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
+                    int act, float alpha, void* stream);
+
 /* MFMA weight gradient of a stride-2 block: dw[16][Cg][Cd] (f32) = sum over pixels.  The pixel sum is
  * split over `msplit` workgroups per tile; partial slabs go to `workspace`
  * (p2p_wgemm_workspace_bytes) and are reduced deterministically. */

@@ -223,6 +223,38 @@ __device__ __forceinline__ void mask_vload8(const unsigned char* m, float* keep,
     }
 }
 
+// Column totals of two per-thread partial vectors over the PR pixel rows of a 256-thread workgroup (fixed order, so
+// deterministic).  Three short LDS stages instead of every thread re-adding all PR rows: (1) partials to red[.][pr][CG],
+// (2) thread (q, ch) adds rows q, q+Q, ... (Q = 256 / CG, i.e. VN rows each), (3) the first CG threads add the Q
+// part-sums and publish them at red[.][256 + ch].
+template <int VN>
+__device__ __forceinline__ void col_reduce2(float (*red)[2048], int CG, int PR, int vid, int pr, const float* s1,
+                                            const float* s2, float* t1, float* t2) {
+#pragma unroll
+    for (int k = 0; k < VN; k += 4) {
+        *(f32x4*)&red[0][pr * CG + vid * VN + k] = f32x4{s1[k], s1[k + 1], s1[k + 2], s1[k + 3]};
+        *(f32x4*)&red[1][pr * CG + vid * VN + k] = f32x4{s2[k], s2[k + 1], s2[k + 2], s2[k + 3]};
+    }
+    __syncthreads();
+    const int Q = 256 / CG;
+    const int ch = threadIdx.x % CG, q = threadIdx.x / CG;
+    float a = 0.f, b = 0.f;
+    for (int i = q; i < PR; i += Q) { a += red[0][i * CG + ch]; b += red[1][i * CG + ch]; }
+    __syncthreads();
+    red[0][q * CG + ch] = a;
+    red[1][q * CG + ch] = b;
+    __syncthreads();
+    if (threadIdx.x < CG) {
+        float ta = 0.f, tb = 0.f;
+        for (int i = 0; i < Q; ++i) { ta += red[0][i * CG + threadIdx.x]; tb += red[1][i * CG + threadIdx.x]; }
+        red[0][256 + threadIdx.x] = ta;
+        red[1][256 + threadIdx.x] = tb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { t1[k] = red[0][256 + vid * VN + k]; t2[k] = red[1][256 + vid * VN + k]; }
+}
+
 // MODE 0: one launch per layer (statistics + apply, grid.z = 1 when normalising).
 // MODE 1 / 2: the pixel range of every image is split over grid.z workgroups; launch 1 writes per-split partial
 // sums to ws[N][SP][C][2], launch 2 adds them up (fixed order: deterministic) and applies.  Used when one workgroup
@@ -236,7 +268,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
                                                         T* __restrict__ raw_out, float* __restrict__ stats,
                                                         float* __restrict__ ws, int nslots) {
     constexpr int VN = VecOf<T>::N;
-    __shared__ float red[2][2048];      // [2][PR][CG], PR * CG = 256 * VN <= 2048
+    __shared__ __attribute__((aligned(16))) float red[2][2048];      // [2][PR][CG], PR * CG = 256 * VN <= 2048
     const int n = blockIdx.x;
     const int cg0 = blockIdx.y * CG;
     const int SP = gridDim.z, sp = blockIdx.z;
@@ -261,14 +293,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
 #pragma unroll
                 for (int k = 0; k < VN; ++k) { float d = x[k] - sh[k]; s1[k] += d; s2[k] += d * d; }
             }
-#pragma unroll
-            for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < VN; ++k) {
-                t1[k] = 0.f; t2[k] = 0.f;
-                for (int i = 0; i < PR; ++i) { t1[k] += red[0][i * CG + vid * VN + k]; t2[k] += red[1][i * CG + vid * VN + k]; }
-            }
+            col_reduce2<VN>(red, CG, PR, vid, pr, s1, s2, t1, t2);
             if (MODE == 1) {
                 if (pr == 0)
 #pragma unroll
@@ -354,7 +379,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
                                                         TView draw, float* __restrict__ dgamma_part,
                                                         float* __restrict__ dbeta_part, float* __restrict__ ws) {
     constexpr int VN = VecOf<T>::N;
-    __shared__ float red[2][2048];
+    __shared__ __attribute__((aligned(16))) float red[2][2048];
     const int n = blockIdx.x;
     const int cg0 = blockIdx.y * CG;
     const int SP = gridDim.z, sp = blockIdx.z;
@@ -405,14 +430,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
 #pragma unroll
             for (int k = 0; k < VN; ++k) { s1[k] += d[k]; s2[k] += d[k] * xh[k]; }
         }
-#pragma unroll
-        for (int k = 0; k < VN; ++k) { red[0][pr * CG + vid * VN + k] = s1[k]; red[1][pr * CG + vid * VN + k] = s2[k]; }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < VN; ++k) {
-            t1[k] = 0.f; t2[k] = 0.f;
-            for (int i = 0; i < PR; ++i) { t1[k] += red[0][i * CG + vid * VN + k]; t2[k] += red[1][i * CG + vid * VN + k]; }
-        }
+        col_reduce2<VN>(red, CG, PR, vid, pr, s1, s2, t1, t2);
         if (MODE == 1) {
             if (pr == 0)
 #pragma unroll

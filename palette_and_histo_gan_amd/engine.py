@@ -255,7 +255,10 @@ class Pix2PixEngine:
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
-        self.use_conv_edge = os.environ.get("P2P_CONV_EDGE", "1") != "0"      # LDS-resident edge convolutions
+        # LDS-resident edge convolutions: measured 10-30% slower than the implicit-GEMM edge path on every c2 shape (r01),
+        # so opt-in until the kernel overlaps its strip loads with the MFMA loop
+        self.use_conv_edge = os.environ.get("P2P_CONV_EDGE", "0") != "0"
+        self.use_conv_fewout = os.environ.get("P2P_CONV_FEWOUT", "1") != "0"    # 1..4-output heads: tap-major GEMM + shifted sum
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self.refresh_weight_copies()
 
@@ -486,8 +489,12 @@ class Pix2PixEngine:
                 cin_pad, nc, rows, w = lw.hi_pad, cd, up32(cd), _p(lw.wt)
             else:
                 cin_pad, nc, rows, w = lw.lo_pad, (ncols or cg), up32(cg), self._wn(sid, name)
-            entry = "p2p_conv_edge" if self.use_conv_edge and L.lib().p2p_conv_edge_ok(op, stride, self.dtype, N, lh, lh, cin_pad, nc) \
-                else "p2p_igemm_edge"
+            if self.use_conv_fewout and L.lib().p2p_conv_fewout_ok(op, stride, self.dtype, N, lh, lh, cin_pad, nc):
+                entry = "p2p_conv_fewout"
+            elif self.use_conv_edge and L.lib().p2p_conv_edge_ok(op, stride, self.dtype, N, lh, lh, cin_pad, nc):
+                entry = "p2p_conv_edge"
+            else:
+                entry = "p2p_igemm_edge"
             L.call(entry, op, stride, self.dtype, N, lh, lh, cin_pad, nc, rows, C.byref(in_view),
                    C.byref(out_view), w, bias if bias is not None else NULL, act, LEAKY_ALPHA, _stream())
             return (1, 1)

@@ -261,6 +261,30 @@ def _pad_view_input(x, cpad, dtype):
     return U.halo_from(xp, dtype)
 
 
+def _pick_edge_entry(entry, op, stride, dtype, n, lh, cin_pad, nc):
+    """The specialised edge kernels cover part of the shape space; like the engine, fall back to p2p_igemm_edge."""
+    if entry == "p2p_igemm_edge":
+        return entry
+    ok = getattr(L.lib(), entry + "_ok")(op, stride, dtype, n, lh, lh, cin_pad, nc)
+    return entry if ok else "p2p_igemm_edge"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lh,cg,cd,stride,g_ok,p_ok", [
+    (2, 64, 36, 4, 1, True, False),      # generator head 36(+4) -> 4, stride 1
+    (3, 32, 64, 1, 1, True, False),      # discriminator head 64 -> 1
+    (2, 32, 4, 64, 2, False, True),      # d(discriminator first conv)/d(fake image): 64 -> 4, transposed stride 2
+    (2, 16, 1, 64, 2, False, True),      # indexed model: 64 -> 1
+    (1, 128, 33, 3, 1, True, False),     # 128-pixel rows, 3 real output channels
+    (5, 8, 60, 2, 1, True, False)])
+def test_edge_layers_few_outputs(dtype, n, lh, cg, cd, stride, g_ok, p_ok):
+    """Same layers through p2p_conv_fewout (tap-major GEMM + shifted sum out of LDS)."""
+    hi_pad, lo_pad = E.pad8(cg), E.pad8(cd)
+    assert bool(L.lib().p2p_conv_fewout_ok(L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd)) == g_ok
+    assert bool(L.lib().p2p_conv_fewout_ok(L.OP_P, stride, dtype, n, lh, lh, lo_pad, min(cg, 32))) == p_ok
+    test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_conv_fewout")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,stride", [(2, 32, 4, 64, 2), (3, 32, 8, 64, 2), (2, 64, 36, 4, 1), (2, 32, 64, 1, 1),
                                                 (2, 16, 1, 64, 2), (5, 16, 33, 8, 1)])
@@ -289,10 +313,7 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_igemm_edge
     # op G with bias + LeakyReLU into a channel slice of a wider haloed buffer
     out_g = E.HaloBuf(n, lh, lh, cd + 8, dtype, U.DEV)
     bias_d = U.dev(bias)
-    e_g = entry
-    if entry == "p2p_conv_edge" and not L.lib().p2p_conv_edge_ok(L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd):
-        assert dtype == L.F32 and hi_pad >= 64       # only the f32 copy of a 64-channel layer exceeds the LDS weight budget
-        e_g = "p2p_igemm_edge"
+    e_g = _pick_edge_entry(entry, L.OP_G, stride, dtype, n, lh, hi_pad, cd)
     L.call(e_g, L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd, E.up32(cd), C.byref(hi_b.view()),
            C.byref(out_g.view(coff=8)), U.ptr(wt), U.ptr(bias_d), L.ACT_LEAKY, 0.3, U.stream())
     want = g_ref + bias
@@ -304,10 +325,7 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_igemm_edge
     ncols = min(cg, 32)
     out_p = E.DenseBuf(n, stride * lh, stride * lh, hi_pad, U.tdt(dtype), U.DEV)
     out_p.t.zero_()
-    e_p = entry
-    if entry == "p2p_conv_edge" and not L.lib().p2p_conv_edge_ok(L.OP_P, stride, dtype, n, lh, lh, lo_pad, ncols):
-        assert dtype == L.F32 and lo_pad >= 64
-        e_p = "p2p_igemm_edge"
+    e_p = _pick_edge_entry(entry, L.OP_P, stride, dtype, n, lh, lo_pad, ncols)
     L.call(e_p, L.OP_P, stride, dtype, n, lh, lh, lo_pad, ncols, E.up32(cg), C.byref(lo_b.view()),
            C.byref(out_p.view()), U.ptr(wn), None, L.ACT_NONE, 0.0, U.stream())
     gp = U.dense_to_np(out_p)
