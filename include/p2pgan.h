@@ -131,8 +131,9 @@ int p2p_wgemm_edge(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd,
 
 /* LDS-resident form for the edge layers (Cg, Cd <= 64 with at most two 32x32 tiles, LW in {16,32,64}): every strip of
  * pixels is staged once and all 16 taps are contracted out of LDS, so HBM traffic = the algorithmic bytes.
- * p2p_wgrad_small_blocks returns the number of f32 partial slabs the call needs in `workspace`
- * (blocks * 16*Cg*Cd floats), or 0 if the shape is not supported (use p2p_wgemm_edge). */
+ * p2p_wgrad_small_blocks returns the number of f32 slabs of 16*Cg*Cd floats the call needs in `workspace` (one partial
+ * per workgroup plus the intermediate slabs of the two-level fixed-order sum), or 0 if the shape is not supported
+ * (use p2p_wgemm_edge). */
 int p2p_wgrad_small_blocks(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld);
 int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd,
                     const p2p_tensor* hi, const p2p_tensor* lo, float* dw, void* workspace, void* stream);
@@ -181,16 +182,22 @@ int p2p_colsum_batched(const float* part, const int* table, int ntasks, int max_
 
 /* ---- losses (pix2pix_model.py:44-56) ------------------------------------------------------------ */
 
+/* Loss sums are deterministic: the loss kernels launch P2P_LOSS_BLOCKS workgroups and write one partial per workgroup
+ * and loss term, partials[k * P2P_LOSS_BLOCKS + b]; p2p_loss_partials_sum adds K consecutive rows in workgroup order,
+ * out[k] = sum_b partials[k * P2P_LOSS_BLOCKS + b] (one launch for all loss terms of a step). */
+#define P2P_LOSS_BLOCKS 256
+int p2p_loss_partials_sum(const float* partials, int K, float* out, void* stream);
+
 /* logits: view [N2][H][W][1]; images [0,n_real) are D(real), the rest D(fake).
- * loss_out[0..2] = sums of BCE(1,real), BCE(0,fake), BCE(1,fake) scaled by inv_count.
+ * partials rows 0..2 = BCE(1,real), BCE(0,fake), BCE(1,fake) scaled by inv_count.
  * dlogits_d (all N2 images): d(real+fake loss)/dlogit; dlogits_g (fake images only): d(adv)/dlogit. */
 int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits,
                    float inv_count, const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g,
-                   float* loss_out, void* stream);
+                   float* partials, void* stream);
 
-/* fake = tanh(z) written to `fake` view; l1_out[0] = inv_count * sum |real - fake| over all C channels. */
+/* fake = tanh(z) written to `fake` view; partials row 0 = inv_count * sum |real - fake| over all C channels. */
 int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* real,
-                    const p2p_tensor* fake, float inv_count, float* l1_out, void* stream);
+                    const p2p_tensor* fake, float inv_count, float* partials, void* stream);
 
 /* dz = (g_d + g_extra + lambda_l1*inv_count*sign(fake-real)) * (1 - fake^2) into the haloed view dz. */
 int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,

@@ -38,6 +38,7 @@ struct IgemmArgs {
     // fused InstanceNorm statistics (VEPI epilogue): per (image, slot, channel) the mean and the centred sum of squares
     // of `stat_rows` consecutive output pixels of one image; slot = phase * tiles_per_image + tile_in_image
     float* stat_part; int stat_rows; int stat_slots; int lgHW;
+    int flags;           // tuning: bit 0 = spread the next K-block's LDS-DMA pieces over the four k-steps, bit 1 = s_setprio around MFMAs
 };
 
 template <typename T> struct Frag;
@@ -126,21 +127,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         }
     };
 
-    auto stage = [&](int kb, char* buf) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int tl, cbyte, dy, dx, widx;
-            split_k(kb, aq[i], tl, cbyte);
+    constexpr int NL = NA + NB;                   // LDS-DMA instructions ("pieces") per thread per stage
+    auto stage_piece = [&](int kb, char* buf, int p) {
+        int tl, cbyte, dy, dx, widx;
+        if (p < NA) {
+            split_k(kb, aq[p], tl, cbyte);
             tap_geom(tl, dy, dx, widx);
-            glds16(abase[i] + (dy * rowB + dx * pixB + cbyte), buf + (i * 4 + wave) * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            int tl, cbyte, dy, dx, widx;
+            glds16(abase[p] + (dy * rowB + dx * pixB + cbyte), buf + (p * 4 + wave) * 1024);
+        } else {
+            const int j = p - NA;
             split_k(kb, bq[j], tl, cbyte);
             tap_geom(tl, dy, dx, widx);
             glds16(a.w + (widx * wtap + bbase[j] + cbyte), buf + A_BYTES + (j * 4 + wave) * 1024);
         }
+    };
+    auto stage = [&](int kb, char* buf) {
+#pragma unroll
+        for (int p = 0; p < NL; ++p) stage_piece(kb, buf, p);
     };
 
     // accumulators: weights are the MFMA "A" operand (rows = output channel), pixels the "B" operand
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     // NST = 3: ring of three LDS stages, two K-blocks of loads in flight across the barrier: a counted s_waitcnt leaves
     //          the younger stage's LDS-DMA outstanding (cdna_hip_programming.md "Pipelining across barriers") -- for
     //          launches that put a single workgroup on each CU.
-    constexpr int NL = NA + NB;                   // LDS-DMA instructions per thread per stage
+    const bool ilv = a.flags & 1, prio = a.flags & 2;
     stage(0, smem);
     if (NST == 3 && nkb > 1) stage(1, smem + STAGE);
     for (int kb = 0; kb < nkb; ++kb) {
@@ -181,10 +184,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             __syncthreads();
         }
         char* cur = smem + (NST == 3 ? (kb % 3) : (kb & 1)) * STAGE;
-        if (NST == 3) { if (kb + 2 < nkb) stage(kb + 2, smem + ((kb + 2) % 3) * STAGE); }
-        else if (kb + 1 < nkb) stage(kb + 1, smem + ((kb + 1) & 1) * STAGE);
+        const int kn = NST == 3 ? kb + 2 : kb + 1;                   // K-block to prefetch
+        char* nxt = smem + (NST == 3 ? (kn % 3) : (kn & 1)) * STAGE;
+        if (!ilv && kn < nkb) stage(kn, nxt);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (ilv && kn < nkb) {
+#pragma unroll
+                for (int p = (s * NL) / 4; p < ((s + 1) * NL) / 4; ++p) stage_piece(kn, nxt, p);
+            }
             frag_t af[TM], bf[TN];
             const int q = 2 * s + h;
 #pragma unroll
@@ -193,10 +201,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[j] = *(const frag_t*)(cur + A_BYTES + brow[j] * 128 + ((q ^ ((brow[j] >> 1) & 7)) << 4));
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mfma_step(acc[i][j], bf[j], af[i]);
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -331,6 +341,13 @@ static int ilog2_exact(long long v) {
     return (1LL << l) == v ? l : -1;
 }
 
+static int igemm_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int igemm_flags() { static int v = -1; if (v < 0) v = igemm_env("P2P_IGEMM_FLAGS", 0); return v; }
+static int igemm_big() { static int v = -1; if (v < 0) v = igemm_env("P2P_IGEMM_BIG", 0); return v; }
+
 static int igemm_stage_override() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("P2P_IGEMM_STAGES"); v = e ? atoi(e) : 0; }
@@ -374,7 +391,10 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
     unsigned gz = (unsigned)(phases * a.splitk);
     const int ctiles = (a.ncols + 31) / 32 * 32;      // launched columns (<= w_rows)
     const bool bigM = a.M >= 256 * 512;                // enough rows to fill the chip with 256-row tiles
-    if (ctiles % 128 == 0) igemm_go<T, 2, 2, 2, 2, GEN>(a, gz, vepi, st);
+    a.flags = igemm_flags();
+    if (ctiles % 128 == 0 && igemm_big() && !a.stat_part && (long long)((a.M + 255) / 256) * (ctiles / 128) * gz >= igemm_big())
+        igemm_go<T, 2, 2, 4, 2, GEN>(a, gz, vepi, st);
+    else if (ctiles % 128 == 0) igemm_go<T, 2, 2, 2, 2, GEN>(a, gz, vepi, st);
     else if (ctiles % 64 == 0) {
         if (bigM) igemm_go<T, 4, 1, 2, 2, GEN>(a, gz, vepi, st);
         else igemm_go<T, 2, 2, 2, 1, GEN>(a, gz, vepi, st);

@@ -7,111 +7,138 @@ __device__ __forceinline__ float bce_logit(float x, float z) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-// loss_out[0] += BCE(1, real) ; [1] += BCE(0, fake) ; [2] += BCE(1, fake)   (all scaled by inv_count)
+// partials[k * P2P_LOSS_BLOCKS + b] = workgroup b's share of k = 0: BCE(1, real), 1: BCE(0, fake), 2: BCE(1, fake)
+// (scaled by inv_count); p2p_loss_partials_sum adds them in workgroup order
 template <typename T>
-__global__ void bce_logits_kernel(int N2, int n_real, int H, int W, TView logits, float inv_count, TView dld,
-                                  TView dlg, float* __restrict__ loss_out) {
+__global__ __launch_bounds__(256) void bce_logits_kernel(int N2, int n_real, PixDec dec, TView logits, float inv_count, TView dld,
+                                                         TView dlg, float* __restrict__ partials) {
     __shared__ float red[16];
-    long long total = (long long)N2 * H * W;
-    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        int x = (int)(i % W);
-        int y = (int)((i / W) % H);
-        int n = (int)(i / ((long long)W * H));
+    const unsigned total = (unsigned)N2 * dec.H * dec.W;
+    float l[3] = {0.f, 0.f, 0.f};
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(i, n, y, x);
         float v = to_f32(((const T*)logits.ptr)[logits.off(n, y, x)]);
         float s = sigmoidf(v);
         if (n < n_real) {
-            l0 += bce_logit(v, 1.f);
+            l[0] += bce_logit(v, 1.f);
             ((T*)dld.ptr)[dld.off(n, y, x)] = from_f32<T>((s - 1.f) * inv_count);
         } else {
-            l1 += bce_logit(v, 0.f);
-            l2 += bce_logit(v, 1.f);
+            l[1] += bce_logit(v, 0.f);
+            l[2] += bce_logit(v, 1.f);
             ((T*)dld.ptr)[dld.off(n, y, x)] = from_f32<T>(s * inv_count);
             if (dlg.ptr) ((T*)dlg.ptr)[dlg.off(n - n_real, y, x)] = from_f32<T>((s - 1.f) * inv_count);
         }
     }
-    l0 = block_sum(l0, red);
-    l1 = block_sum(l1, red);
-    l2 = block_sum(l2, red);
-    if (threadIdx.x == 0) {
-        atomicAdd(loss_out + 0, l0 * inv_count);
-        atomicAdd(loss_out + 1, l1 * inv_count);
-        atomicAdd(loss_out + 2, l2 * inv_count);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        l[k] = block_sum(l[k], red);
+        if (threadIdx.x == 0) partials[k * P2P_LOSS_BLOCKS + blockIdx.x] = l[k] * inv_count;
     }
 }
 
-template <typename T>
-__global__ void tanh_l1_fwd_kernel(int N, int H, int W, int C, TView z, TView real, TView fake, float inv_count,
-                                   float* __restrict__ l1_out) {
+// fake = tanh(z), L1 partial.  VEC: 4 channels per lane as one 8/16-byte access per view (RGBA head).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void tanh_l1_fwd_kernel(int N, PixDec dec, int C, TView z, TView real, TView fake, float inv_count,
+                                                          float* __restrict__ partials) {
     __shared__ float red[16];
-    long long total = (long long)N * H * W * C;
+    typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+    const unsigned npix = (unsigned)N * dec.H * dec.W;
     float acc = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long long p = i / C;
-        int x = (int)(p % W);
-        int y = (int)((p / W) % H);
-        int n = (int)(p / ((long long)W * H));
-        float f = tanhf(to_f32(((const T*)z.ptr)[z.off(n, y, x) + c]));
-        T fq = from_f32<T>(f);
-        ((T*)fake.ptr)[fake.off(n, y, x) + c] = fq;
-        acc += fabsf(to_f32(((const T*)real.ptr)[real.off(n, y, x) + c]) - to_f32(fq));
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(p, n, y, x);
+        const T* zp = (const T*)z.ptr + z.off(n, y, x);
+        const T* rp = (const T*)real.ptr + real.off(n, y, x);
+        T* fp = (T*)fake.ptr + fake.off(n, y, x);
+        if (VEC) {
+            const vec4_t zv = *(const vec4_t*)zp, rv = *(const vec4_t*)rp;
+            vec4_t fv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                T fq = from_f32<T>(tanhf(to_f32((T)zv[c])));
+                fv[c] = fq;
+                acc += fabsf(to_f32((T)rv[c]) - to_f32(fq));
+            }
+            *(vec4_t*)fp = fv;
+        } else {
+            for (int c = 0; c < C; ++c) {
+                T fq = from_f32<T>(tanhf(to_f32(zp[c])));
+                fp[c] = fq;
+                acc += fabsf(to_f32(rp[c]) - to_f32(fq));
+            }
+        }
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(l1_out, acc * inv_count);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc * inv_count;
+}
+
+// out[k] = sum_b partials[k * P2P_LOSS_BLOCKS + b], fixed order
+__global__ __launch_bounds__(P2P_LOSS_BLOCKS) void loss_partials_sum_kernel(const float* __restrict__ partials, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = block_sum(partials[blockIdx.x * P2P_LOSS_BLOCKS + threadIdx.x], red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 template <typename T>
-__global__ void tanh_l1_bwd_kernel(int N, int H, int W, int C, TView fake, TView real, GSrc gd, GSrc gx,
+__global__ void tanh_l1_bwd_kernel(int N, PixDec dec, int C, TView fake, TView real, GSrc gd, GSrc gx,
                                    float l1_scale, TView dz) {
-    long long total = (long long)N * H * W * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long long p = i / C;
-        int x = (int)(p % W);
-        int y = (int)((p / W) % H);
-        int n = (int)(p / ((long long)W * H));
-        float f = to_f32(((const T*)fake.ptr)[fake.off(n, y, x) + c]);
-        float r = to_f32(((const T*)real.ptr)[real.off(n, y, x) + c]);
-        float d = f - r;
-        float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);     // tf.abs gradient = sign(x), 0 at 0
-        float g = gsrc_load<T>(gd, p, c) + gsrc_load<T>(gx, p, c) + l1_scale * sgn;
-        ((T*)dz.ptr)[dz.off(n, y, x) + c] = from_f32<T>(g * (1.f - f * f));
+    const unsigned npix = (unsigned)N * dec.H * dec.W;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(p, n, y, x);
+        const T* fp = (const T*)fake.ptr + fake.off(n, y, x);
+        const T* rp = (const T*)real.ptr + real.off(n, y, x);
+        T* dp = (T*)dz.ptr + dz.off(n, y, x);
+        for (int c = 0; c < C; ++c) {
+            float f = to_f32(fp[c]);
+            float d = f - to_f32(rp[c]);
+            float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);     // tf.abs gradient = sign(x), 0 at 0
+            float g = gsrc_load<T>(gd, p, c) + gsrc_load<T>(gx, p, c) + l1_scale * sgn;
+            dp[c] = from_f32<T>(g * (1.f - f * f));
+        }
     }
 }
 
-// few workgroups: every one ends in atomics on the same 1-3 loss words
-static inline unsigned grid_for(long long total) {
-    long long b = (total + 1023) / 1024;
-    return (unsigned)(b < 256 ? (b < 1 ? 1 : b) : 256);
+// The loss kernels always launch P2P_LOSS_BLOCKS workgroups (grid-stride loops) and write one partial per workgroup and
+// loss term; p2p_loss_partials_sum turns K consecutive partial rows into K sums (one launch for all loss terms of a step).
+extern "C" int p2p_loss_partials_sum(const float* partials, int K, float* out, void* stream) {
+    P2P_REQUIRE(partials && out && K >= 1 && K <= 64, "p2p_loss_partials_sum: bad args");
+    loss_partials_sum_kernel<<<dim3(K), P2P_LOSS_BLOCKS, 0, (hipStream_t)stream>>>(partials, out);
+    return p2p_check_launch("p2p_loss_partials_sum");
 }
 
 extern "C" int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits, float inv_count,
-                              const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g, float* loss_out, void* stream) {
+                              const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g, float* partials, void* stream) {
     P2P_REQUIRE(N2 > 0 && n_real >= 0 && n_real <= N2 && H > 0 && W > 0, "p2p_bce_logits: bad shape");
-    P2P_REQUIRE(logits && logits->ptr && dlogits_d && dlogits_d->ptr && loss_out, "p2p_bce_logits: null pointer");
+    P2P_REQUIRE(logits && logits->ptr && dlogits_d && dlogits_d->ptr && partials, "p2p_bce_logits: null pointer");
+    P2P_REQUIRE((long long)N2 * H * W < (1LL << 31), "p2p_bce_logits: too many pixels");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(loss_out, 0, 3 * sizeof(float), st);
-    if (e != hipSuccess) { p2p_set_error("p2p_bce_logits memset: %s", hipGetErrorString(e)); return (int)e; }
     TView g;
     if (dlogits_g && dlogits_g->ptr) g = make_view(dlogits_g);
     else { g.ptr = nullptr; g.img = 0; g.row = 0; g.ld = 0; }
-    P2P_DISPATCH_DTYPE(dtype, (bce_logits_kernel<T><<<dim3(grid_for((long long)N2 * H * W)), 256, 0, st>>>(
-                                  N2, n_real, H, W, make_view(logits), inv_count, make_view(dlogits_d), g, loss_out)));
+    P2P_DISPATCH_DTYPE(dtype, (bce_logits_kernel<T><<<dim3(P2P_LOSS_BLOCKS), 256, 0, st>>>(
+                                  N2, n_real, PixDec::make(H, W), make_view(logits), inv_count, make_view(dlogits_d), g, partials)));
     return p2p_check_launch("p2p_bce_logits");
 }
 
 extern "C" int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* real,
-                               const p2p_tensor* fake, float inv_count, float* l1_out, void* stream) {
+                               const p2p_tensor* fake, float inv_count, float* partials, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_tanh_l1_fwd: bad shape");
-    P2P_REQUIRE(z && z->ptr && real && real->ptr && fake && fake->ptr && l1_out, "p2p_tanh_l1_fwd: null pointer");
+    P2P_REQUIRE(z && z->ptr && real && real->ptr && fake && fake->ptr && partials, "p2p_tanh_l1_fwd: null pointer");
+    P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_tanh_l1_fwd: too many pixels");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(l1_out, 0, sizeof(float), st);
-    if (e != hipSuccess) { p2p_set_error("p2p_tanh_l1_fwd memset: %s", hipGetErrorString(e)); return (int)e; }
-    long long tb = ((long long)N * H * W * C + 1023) / 1024;      // 4 elements per thread, one atomic per workgroup
-    if (tb > 1024) tb = 1024;
-    P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_kernel<T><<<dim3((unsigned)(tb < 1 ? 1 : tb)), 256, 0, st>>>(
-                                  N, H, W, C, make_view(z), make_view(real), make_view(fake), inv_count, l1_out)));
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    auto al = [&](const p2p_tensor* t) { return t->ld % 4 == 0 && ((uintptr_t)t->ptr % (4 * esz)) == 0; };
+    const bool vec = C == 4 && al(z) && al(real) && al(fake);
+    const dim3 grid(P2P_LOSS_BLOCKS);
+    if (vec) {
+        P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_kernel<T, true><<<grid, 256, 0, st>>>(N, PixDec::make(H, W), C, make_view(z), make_view(real),
+                                                                                    make_view(fake), inv_count, partials)));
+    } else {
+        P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_kernel<T, false><<<grid, 256, 0, st>>>(N, PixDec::make(H, W), C, make_view(z), make_view(real),
+                                                                                     make_view(fake), inv_count, partials)));
+    }
     return p2p_check_launch("p2p_tanh_l1_fwd");
 }
 
@@ -120,10 +147,11 @@ extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_
                                void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_tanh_l1_bwd: bad shape");
     P2P_REQUIRE(fake && fake->ptr && real && real->ptr && dz && dz->ptr, "p2p_tanh_l1_bwd: null pointer");
-    long long blocks = ((long long)N * H * W * C + 255) / 256;
+    P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_tanh_l1_bwd: too many pixels");
+    long long blocks = ((long long)N * H * W + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
-                                  N, H, W, C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
+                                  N, PixDec::make(H, W), C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
                                   l1_scale, make_view(dz))));
     return p2p_check_launch("p2p_tanh_l1_bwd");
 }

@@ -473,22 +473,42 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
 // Batched column sums: task t reduces part[off_t .. off_t + rows*cols) (dense [rows][cols]) over rows into
 // out[out_off_t .. + cols).  table = int32[ntasks][4] = {part_off, rows, cols, out_off} on the device.
 // One launch replaces the per-layer dgamma/dbeta reductions of a whole backward pass.
-__global__ void colsum_batched_kernel(const float* __restrict__ part, const int* __restrict__ table,
-                                      float* __restrict__ out) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const float* __restrict__ part, const int* __restrict__ table,
+                                                             float* __restrict__ out) {
+    // 16 column quads (64 columns) x 16 row groups per workgroup; a lane adds rows rg, rg+16, ... of its 4 columns with
+    // 16-byte loads (cols % 4 == 0: channel counts), the 16 groups are combined through LDS in a fixed order
+    __shared__ f32x4 red[16][16];
     const int* t = table + 4 * blockIdx.y;
     const int poff = t[0], rows = t[1], cols = t[2], ooff = t[3];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = rg; r < rows; r += 4) s += part[(long long)poff + (long long)r * cols + c];
-    red[rg][threadIdx.x & 63] = s;
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    if (blockIdx.x * 64 >= cols) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        const float* p = part + (long long)poff + c;
+        if ((cols & 3) == 0 && (poff & 3) == 0) {
+#pragma unroll 4
+            for (int r = rg; r < rows; r += 16) s += *(const f32x4*)(p + (long long)r * cols);
+        } else {
+            for (int r = rg; r < rows; r += 16)
+                for (int k = 0; k < 4; ++k)
+                    if (c + k < cols) s[k] += p[(long long)r * cols + k];
+        }
+    }
+    red[rg][cq] = s;
     __syncthreads();
-    if (rg == 0 && c < cols) out[ooff + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (rg == 0 && c < cols) {
+        f32x4 tsum = red[0][cq];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tsum += red[i][cq];
+        for (int k = 0; k < 4; ++k)
+            if (c + k < cols) out[ooff + c + k] = tsum[k];
+    }
 }
 
 extern "C" int p2p_colsum_batched(const float* part, const int* table, int ntasks, int max_cols, float* out, void* stream) {
     P2P_REQUIRE(part && table && out && ntasks > 0 && max_cols > 0, "p2p_colsum_batched: bad args");
+    P2P_REQUIRE(((uintptr_t)part % 16) == 0, "p2p_colsum_batched: partials must be 16-byte aligned");
     colsum_batched_kernel<<<dim3((max_cols + 63) / 64, ntasks), 256, 0, (hipStream_t)stream>>>(part, table, out);
     return p2p_check_launch("p2p_colsum_batched");
 }

@@ -134,16 +134,17 @@ extern "C" int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* 
 }
 
 template <typename T>
-__global__ void pack_input_kernel(int N, int H, int W, int C, const void* __restrict__ src, int src_is_int, TView dst) {
-    long long total = (long long)N * H * W * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long long p = i / C;
-        int x = (int)(p % W);
-        int y = (int)((p / W) % H);
-        int n = (int)(p / ((long long)W * H));
-        float v = src_is_int ? (float)((const int*)src)[i] : ((const float*)src)[i];
-        ((T*)dst.ptr)[dst.off(n, y, x) + c] = from_f32<T>(v);
+__global__ void pack_input_kernel(int N, PixDec dec, int C, const void* __restrict__ src, int src_is_int, TView dst) {
+    const unsigned npix = (unsigned)N * dec.H * dec.W;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(p, n, y, x);
+        T* d = (T*)dst.ptr + dst.off(n, y, x);
+        const long long e = (long long)p * C;
+        for (int c = 0; c < C; ++c) {
+            float v = src_is_int ? (float)((const int*)src)[e + c] : ((const float*)src)[e + c];
+            d[c] = from_f32<T>(v);
+        }
     }
 }
 
@@ -152,15 +153,14 @@ __global__ void pack_input_kernel(int N, int H, int W, int C, const void* __rest
 struct PackDst { TView v[4]; int n; };
 
 template <typename T>
-__global__ void pack_multi_kernel(int N, int H, int W, int C, const void* __restrict__ src, int src_is_int, PackDst dst) {
-    long long total = (long long)N * H * W;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
-        int x = (int)(p % W);
-        int y = (int)((p / W) % H);
-        int n = (int)(p / ((long long)W * H));
+__global__ void pack_multi_kernel(int N, PixDec dec, int C, const void* __restrict__ src, int src_is_int, PackDst dst) {
+    const unsigned npix = (unsigned)N * dec.H * dec.W;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(p, n, y, x);
         if (C == 4 && !src_is_int) {      // RGBA pixel: one 16-byte read, one 4-channel vector store per view
             typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
-            f32x4 v = *(const f32x4*)((const float*)src + p * 4);
+            f32x4 v = *(const f32x4*)((const float*)src + (long long)p * 4);
             vec4_t q;
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = from_f32<T>(v[k]);
@@ -169,8 +169,9 @@ __global__ void pack_multi_kernel(int N, int H, int W, int C, const void* __rest
                 if (k < dst.n) *(vec4_t*)((T*)dst.v[k].ptr + dst.v[k].off(n, y, x)) = q;
             continue;
         }
+        const long long e = (long long)p * C;
         for (int c = 0; c < C; ++c) {
-            float v = src_is_int ? (float)((const int*)src)[p * C + c] : ((const float*)src)[p * C + c];
+            float v = src_is_int ? (float)((const int*)src)[e + c] : ((const float*)src)[e + c];
             T q = from_f32<T>(v);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -192,9 +193,10 @@ extern "C" int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const
                         "p2p_pack_input_multi: RGBA views must be aligned to 4 channels");
     }
     long long total = (long long)N * H * W;
+    P2P_REQUIRE(total < (1LL << 31), "p2p_pack_input_multi: too many pixels");
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    P2P_DISPATCH_DTYPE(dtype, (pack_multi_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(N, H, W, C, src, src_is_int, d)));
+    P2P_DISPATCH_DTYPE(dtype, (pack_multi_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(N, PixDec::make(H, W), C, src, src_is_int, d)));
     return p2p_check_launch("p2p_pack_input_multi");
 }
 
@@ -236,8 +238,9 @@ static inline unsigned grid_for(long long total) {
 extern "C" int p2p_pack_input(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
                               const p2p_tensor* dst, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && src && dst && dst->ptr, "p2p_pack_input: bad args");
-    P2P_DISPATCH_DTYPE(dtype, (pack_input_kernel<T><<<dim3(grid_for((long long)N * H * W * C)), 256, 0, (hipStream_t)stream>>>(
-                                  N, H, W, C, src, src_is_int, make_view(dst))));
+    P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_pack_input: too many pixels");
+    P2P_DISPATCH_DTYPE(dtype, (pack_input_kernel<T><<<dim3(grid_for((long long)N * H * W)), 256, 0, (hipStream_t)stream>>>(
+                                  N, PixDec::make(H, W), C, src, src_is_int, make_view(dst))));
     return p2p_check_launch("p2p_pack_input");
 }
 

@@ -97,6 +97,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return s;
 }
 
+// Pixel index -> (n, y, x) with 32-bit arithmetic (callers guarantee N*H*W < 2^31): shifts for power-of-two maps
+// (every map of the reference models), one 32-bit division pair otherwise.  64-bit '%' and '/' cost ~100 instructions each.
+struct PixDec {
+    int W, H, lgW, lgH;   // lg* = -1 when not a power of two
+    __host__ __device__ static int lg2(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+    __host__ static PixDec make(int H_, int W_) { PixDec d; d.W = W_; d.H = H_; d.lgW = lg2(W_); d.lgH = lg2(H_); return d; }
+    __device__ __forceinline__ void operator()(unsigned p, int& n, int& y, int& x) const {
+        if (lgW >= 0 && lgH >= 0) { x = p & (W - 1); y = (p >> lgW) & (H - 1); n = p >> (lgW + lgH); }
+        else { unsigned q = p / (unsigned)W; x = p - q * W; n = q / (unsigned)H; y = q - n * H; }
+    }
+};
+
 // XCD-aware block index (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with its
 // own L2, so the blocks b, b+8, b+16, ... share an L2.  This bijective remap hands every XCD one CONTIGUOUS range of the
 // logical block order, so blocks that the caller orders next to each other (same input pixels) hit the same L2.

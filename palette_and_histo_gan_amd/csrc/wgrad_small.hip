@@ -171,16 +171,49 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
     }
 }
 
-__global__ void ws_slab_sum_kernel(const float* __restrict__ part, int nslabs, int n, float* __restrict__ out) {
-    // one workgroup per 64 outputs; 4 slab groups per output reduced through LDS (fixed order)
-    __shared__ float red[4][64];
-    const int o = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
-    float s = 0.f;
-    if (o < n)
-        for (int k = sg; k < nslabs; k += 4) s += part[(long long)k * n + o];
+// Fixed-order sum of partial slabs, four outputs per lane: block (x, y) adds the slabs [y*chunk, (y+1)*chunk) of the 256
+// outputs 256 x .. 256 x + 255 (4 slab lanes per output quad, combined through LDS) into out[y][.].  A second launch
+// with gridDim.y = 1 folds the gridDim.y intermediate slabs, so small outputs (1 K - 8 K values x 512 slabs) are summed
+// by hundreds of workgroups instead of a handful.
+__global__ __launch_bounds__(256) void ws_slab_sum_kernel(const float* __restrict__ part, int nslabs, int n, int chunk,
+                                                          float* __restrict__ out) {
+    __shared__ f32x4 red[4][64];
+    const int c4 = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    const int s0 = blockIdx.y * chunk, s1 = min(nslabs, s0 + chunk);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c4 * 4 < n)
+        for (int k = s0 + sg; k < s1; k += 4) s += *(const f32x4*)(part + (long long)k * n + c4 * 4);
     red[sg][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sg == 0 && o < n) out[o] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (sg == 0 && c4 * 4 < n) {
+        const int l = threadIdx.x;
+        *(f32x4*)(out + (long long)blockIdx.y * n + c4 * 4) = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+    }
+}
+
+// second-level split of the slab sum: enough workgroups to cover the chip, at least 4 slabs per workgroup
+static int ws_sum_split(int nslabs, int n) {
+    const int colblocks = (n / 4 + 63) / 64;
+    int split = 1;
+    while (colblocks * split < 512 && nslabs / (split * 2) >= 4 && split < 64) split *= 2;
+    return split;
+}
+
+#include <stdlib.h>
+static size_t ws_lds_cap() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("P2P_WS_LDS_KB"); v = e ? atol(e) : 150; if (v < 16 || v > 150) v = 150; }
+    return (size_t)v * 1024;
+}
+static long long ws_slab_cap_bytes() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("P2P_WS_SLAB_MB"); v = e ? atol(e) : 64; if (v < 1 || v > 64) v = 64; }
+    return (long long)v << 20;
+}
+static long long ws_blocks_want() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("P2P_WS_BLOCKS"); v = e ? atol(e) : 512; if (v < 32 || v > 4096) v = 512; }
+    return v;
 }
 
 // Tiling of the LDS-resident form: 32x32 MFMA tiles per workgroup (GT x DT <= 4), channel windows, strip height.
@@ -209,14 +242,14 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
         const size_t hi_bytes = (size_t)(stride * TH + 3) * (stride * LW + 3) * hpB;
         const size_t lo_bytes = (size_t)TH * LW * lpB;
         p.shm = ((hi_bytes + 15) & ~(size_t)15) + 256 + lo_bytes + 512;
-        if (p.shm <= 150 * 1024) break;
+        if (p.shm <= ws_lds_cap()) break;
         if (TH == 1) return p;
     }
     p.TH = TH;
     long long strips = (long long)N * (LH / TH);
-    long long want = 512 / (p.gwins * p.dwins);
+    long long want = ws_blocks_want() / (p.gwins * p.dwins);
     const long long slab_bytes = 16LL * Cg * Cd * 4;
-    const long long cap = (64LL << 20) / slab_bytes;         // keep the partial slabs within 64 MB
+    const long long cap = ws_slab_cap_bytes() / slab_bytes;   // keep the partial slabs within 64 MB
     if (want > cap) want = cap;
     if (want < 32) want = 32;
     p.blocks = (int)(strips < want ? strips : want);
@@ -227,7 +260,9 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
 // Applicability / workspace of the LDS-resident form.  Returns the number of partial slabs (workgroups along x) or 0.
 extern "C" int p2p_wgrad_small_blocks(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
     WsPlan p = ws_plan(dtype, stride, N, LH, LW, Cg, Cd, hi_ld, lo_ld);
-    return p.ok ? p.blocks : 0;
+    if (!p.ok) return 0;
+    const int split = ws_sum_split(p.blocks, 16 * Cg * Cd);
+    return p.blocks + (split > 1 ? split : 0);
 }
 
 template <typename T>
@@ -279,6 +314,15 @@ extern "C" int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int
     P2P_DISPATCH_DTYPE(dtype, rc = ws_launch<T>(a, stride, plan, st));
     if (rc) return rc;
     const int n = 16 * Cg * Cd;
-    ws_slab_sum_kernel<<<dim3((n + 63) / 64), 256, 0, st>>>((const float*)workspace, nblocks, n, dw);
+    const int colblocks = (n / 4 + 63) / 64, split = ws_sum_split(nblocks, n);
+    const float* part = (const float*)workspace;
+    if (split == 1) {
+        ws_slab_sum_kernel<<<dim3(colblocks, 1), 256, 0, st>>>(part, nblocks, n, nblocks, dw);
+    } else {
+        float* part2 = (float*)workspace + (long long)nblocks * n;
+        const int chunk = (nblocks + split - 1) / split;
+        ws_slab_sum_kernel<<<dim3(colblocks, split), 256, 0, st>>>(part, nblocks, n, chunk, part2);
+        ws_slab_sum_kernel<<<dim3(colblocks, 1), 256, 0, st>>>(part2, split, n, split, dw);
+    }
     return p2p_check_launch("p2p_wgrad_small reduce");
 }

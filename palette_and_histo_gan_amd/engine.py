@@ -251,6 +251,9 @@ class Pix2PixEngine:
         self.plans = {}
         self.lr, self.beta1, self.beta2, self.adam_eps = 2e-4, 0.5, 0.999, 1e-7   # pix2pix_model.py:28-29
         self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
+        # per-workgroup partials of the loss kernels (include/p2pgan.h P2P_LOSS_BLOCKS): rows 0..2 BCE, row 3 L1 -- the
+        # order of the loss slots, so one p2p_loss_partials_sum fills losses[0..3]; row 4 = discarded (generate())
+        self.loss_part = torch.zeros(5 * 256, dtype=torch.float32, device=self.device)
         self.step_count = 0
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
@@ -459,8 +462,9 @@ class Pix2PixEngine:
             best = max(best, self._msplit(B, lh, cg, cd) * 16 * cg * cd * 4)
         for cg, cd, lh in ((2 * self.in_ch, 64, S // 2), (64, 1, S // 2)):
             best = max(best, self._msplit(2 * B, lh, cg, cd) * 16 * cg * cd * 4)
-        # LDS-resident form: partial slabs of 16*Cg*Cd floats, at most 64 MB (wgrad_small.hip ws_plan)
-        return max(best, (64 << 20) + 16)
+        # LDS-resident form: partial slabs of 16*Cg*Cd floats, at most 64 MB, plus <= 64 second-level slabs of the
+        # small layers (wgrad_small.hip ws_plan / ws_sum_split)
+        return max(best, (68 << 20) + 16)
 
     # ------------------------------------------------------------------ kernel wrappers
     def _conv(self, P, op, sid, name, N, lh, in_view, out_view, stride=2, ncols=None, bias=None, act=L.ACT_NONE,
@@ -694,7 +698,7 @@ class Pix2PixEngine:
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
         inv_l1 = 1.0 / (Bg * S * S * self.out_ch)
         L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
-               C.byref(fake_view), inv_l1, _p(self.losses, 3), _stream())
+               C.byref(fake_view), inv_l1, _p(self.loss_part, 3 * 256), _stream())
         g_extra = None
         if lambda_hist is not None:
             # the histogram loss only needs `fake`: its kernels (f32 MFMA, ~1.8 ms at B=256) run on the side stream,
@@ -706,7 +710,7 @@ class Pix2PixEngine:
         h2 = S // 2
         inv_bce = 1.0 / (Bg * h2 * h2)
         L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), inv_bce,
-               C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.losses, 0), _stream())
+               C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.loss_part), _stream())
         P["skip_g_through_d"] = False
         self.discriminator_backward(P, B)
         if lambda_hist is not None:
@@ -790,6 +794,7 @@ class Pix2PixEngine:
 
     def _finish_step(self, P, lambda_l1, lambda_hist, apply_update):
         self.side.join()
+        L.call("p2p_loss_partials_sum", _p(self.loss_part), 4, _p(self.losses), _stream())
         self._reduce_tail()
         if apply_update:
             self.apply_adam()
@@ -893,11 +898,12 @@ class Pix2PixEngine:
         self.discriminator_forward(P, 2 * B)
         h2 = S // 2
         L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), 1.0 / (Bg * h2 * h2),
-               C.byref(P["dld"].view()), None, _p(self.losses, 0), _stream())
+               C.byref(P["dld"].view()), None, _p(self.loss_part), _stream())
         P["skip_g_through_d"] = True
         self.discriminator_backward(P, B)
         self.generator_backward(P)
         self.side.join()
+        L.call("p2p_loss_partials_sum", _p(self.loss_part), 3, _p(self.losses), _stream())
         self._reduce_tail()
         if apply_update:
             self.apply_adam()
@@ -994,7 +1000,7 @@ class Pix2PixEngine:
         fake_view = P["dcat"].view(coff=0, n0=B)
         # tanh through the loss kernel (its L1 output lands in a scratch slot and is ignored)
         L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(fake_view),
-               C.byref(fake_view), 0.0, _p(self.losses, 15), _stream())
+               C.byref(fake_view), 0.0, _p(self.loss_part, 4 * 256), _stream())
         out = torch.empty((B, S, S, self.out_ch), dtype=torch.float32, device=self.device)
         L.call("p2p_unpack", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), _p(out), _stream())
         return out

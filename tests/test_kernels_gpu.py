@@ -181,8 +181,10 @@ def test_losses(dtype):
     dld, dlg = E.HaloBuf(n2, h, h, 1, dtype, U.DEV), E.HaloBuf(n2 - nr, h, h, 1, dtype, U.DEV)
     loss = torch.zeros(8, dtype=torch.float32, device=U.DEV)
     inv = 1.0 / (nr * h * h)
+    part = torch.full((4 * 256,), float("nan"), dtype=torch.float32, device=U.DEV)     # rows 0..2 BCE, row 3 L1
     L.call("p2p_bce_logits", dtype, n2, nr, h, h, C.byref(lb.view()), inv, C.byref(dld.view()), C.byref(dlg.view()),
-           U.ptr(loss), U.stream())
+           U.ptr(part), U.stream())
+    L.call("p2p_loss_partials_sum", U.ptr(part), 3, U.ptr(loss), U.stream())
     lt = torch.tensor(logits, dtype=F64, requires_grad=True)
     real, fake, adv = rg.bce_from_logits(lt[:nr], 1.0), rg.bce_from_logits(lt[nr:], 0.0), rg.bce_from_logits(lt[nr:], 1.0)
     got = loss.cpu().numpy()
@@ -193,15 +195,17 @@ def test_losses(dtype):
     assert U.rel_err(U.halo_to_np(dld), gd) < tol
     assert U.rel_err(U.halo_to_np(dlg), gg) < tol
 
-    n, s, c = 2, 8, 4
+    n, s, c = 3, 16, 4
     z = U.q(rng.normal(size=(n, s, s, c)), dtype)
     real_img = U.q(rng.uniform(-1, 1, size=(n, s, s, c)), dtype)
     gd_src = U.q(rng.normal(size=(n, s, s, 8)), dtype)
     zb, rb = U.halo_from(z, dtype), U.halo_from(real_img, dtype)
     fb, dzb = E.HaloBuf(n, s, s, c, dtype, U.DEV), E.HaloBuf(n, s, s, c, dtype, U.DEV)
     inv = 1.0 / (n * s * s * c)
+    l1_row = part[3 * 256:]
     L.call("p2p_tanh_l1_fwd", dtype, n, s, s, c, C.byref(zb.view()), C.byref(rb.view()), C.byref(fb.view()), inv,
-           U.ptr(loss[3:]), U.stream())
+           U.ptr(l1_row), U.stream())
+    L.call("p2p_loss_partials_sum", U.ptr(part), 4, U.ptr(loss), U.stream())
     zt = torch.tensor(z, dtype=F64, requires_grad=True)
     fake_t = torch.tanh(zt)
     l1 = (torch.tensor(real_img, dtype=F64) - fake_t).abs().mean()
