@@ -261,6 +261,21 @@ int p2p_weight_prep(int dtype, const float* w, int Cg, int Cd, void* wn, void* w
 int p2p_weight_prep_pad(int dtype, const float* w, int Cg, int Cd, void* wn, int wn_rows, int wn_cols,
                         void* wt, int wt_rows, int wt_cols, void* stream);
 
+/* Batched form: one launch for every layer.  `tasks_dev` is a DEVICE array of ntasks (<= 64) descriptors with the
+ * arguments of p2p_weight_prep_pad (null wn / wt = not wanted); tiles_g, tiles_d and the task's workgroup count come from
+ * p2p_weight_prep_task_blocks, first_block is the running sum of the preceding tasks' counts, total_blocks the sum. */
+typedef struct p2p_prep_task {
+    const float* w;
+    void* wn;
+    void* wt;
+    int Cg, Cd, wn_rows, wn_cols, wt_rows, wt_cols, tiles_g, tiles_d;
+    long long first_block;
+} p2p_prep_task;
+long long p2p_weight_prep_task_blocks(int Cg, int Cd, int wn_rows, int wn_cols, int wt_rows, int wt_cols,
+                                      int have_wn, int have_wt, int* tiles_g, int* tiles_d);
+int p2p_weight_prep_batched(int dtype, const p2p_prep_task* tasks_dev, int ntasks, long long total_blocks, void* stream);
+
+
 /* dense f32 (or i32 if src_is_int) [N][H][W][C] host-layout batch -> view in `dtype` (dataset_utils.py:39-48 contract). */
 int p2p_pack_input(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
                    const p2p_tensor* dst, void* stream);

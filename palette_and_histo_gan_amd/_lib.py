@@ -53,6 +53,7 @@ SIGNATURES = {
     "p2p_counter_add": [_vp, _ll, _vp],
     "p2p_dropout_mask_dev": [_vp, _ll, _ll, _vp, _ll, _vp],
     "p2p_weight_prep": [_i, _vp, _i, _i, _vp, _vp, _vp],
+    "p2p_weight_prep_batched": [_i, _vp, _i, _ll, _vp],
     "p2p_pack_input": [_i, _i, _i, _i, _i, _vp, _i, _TP, _vp],
     "p2p_pack_input_multi": [_i, _i, _i, _i, _i, _vp, _i, _TP, _i, _vp],
     "p2p_finish_losses": [_vp, _i, _i, _f, _f, _vp, _vp],
@@ -71,7 +72,16 @@ SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
            "p2p_conv_edge_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_fewout_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgrad_small_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
-           "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong)}
+           "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong),
+           "p2p_weight_prep_task_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_longlong)}
+
+
+class PrepTask(C.Structure):
+    """include/p2pgan.h p2p_prep_task"""
+    _fields_ = [("w", C.c_void_p), ("wn", C.c_void_p), ("wt", C.c_void_p),
+                ("Cg", C.c_int), ("Cd", C.c_int), ("wn_rows", C.c_int), ("wn_cols", C.c_int),
+                ("wt_rows", C.c_int), ("wt_cols", C.c_int), ("tiles_g", C.c_int), ("tiles_d", C.c_int),
+                ("first_block", C.c_longlong)]
 
 _lib = None
 

@@ -95,11 +95,9 @@ extern "C" int p2p_counter_add(long long* counter_dev, long long inc, void* stre
 // g < wt_cols; entries outside the real [Cg][Cd] block are written as zeros (channel padding of the edge
 // layers).  32x32 LDS tile transpose per tap.
 template <typename T>
-__global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, T* __restrict__ wn, int wn_rows,
-                                   int wn_cols, T* __restrict__ wt, int wt_rows, int wt_cols) {
-    __shared__ float tile[32][33];
-    int t = blockIdx.z;
-    int g0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
+__device__ __forceinline__ void weight_prep_tile(const float* __restrict__ w, int Cg, int Cd, T* __restrict__ wn, int wn_rows,
+                                                 int wn_cols, T* __restrict__ wt, int wt_rows, int wt_cols, int t, int g0, int d0,
+                                                 float (*tile)[33]) {
     const float* wp = w + (long long)t * Cg * Cd;
     int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int r = ty; r < 32; r += 8) {
@@ -115,6 +113,47 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, 
             if (d < wt_rows && g < wt_cols) wt[((long long)t * wt_rows + d) * wt_cols + g] = from_f32<T>(tile[tx][r]);
         }
     }
+}
+
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, T* __restrict__ wn, int wn_rows,
+                                   int wn_cols, T* __restrict__ wt, int wt_rows, int wt_cols) {
+    __shared__ float tile[32][33];
+    weight_prep_tile<T>(w, Cg, Cd, wn, wn_rows, wn_cols, wt, wt_rows, wt_cols, blockIdx.z, blockIdx.y * 32, blockIdx.x * 32, tile);
+}
+
+// Batched form: one launch re-derives the copies of every layer after an optimizer step.  Workgroup b serves the
+// task whose [first_block, first_block + 16 * tiles_g * tiles_d) range holds b (<= 64 tasks, scanned linearly).
+template <typename T>
+__global__ void weight_prep_batched_kernel(const p2p_prep_task* __restrict__ tasks, int ntasks) {
+    __shared__ float tile[32][33];
+    const long long b = blockIdx.x;
+    int ti = 0;
+    while (ti + 1 < ntasks && tasks[ti + 1].first_block <= b) ++ti;
+    const p2p_prep_task k = tasks[ti];
+    const int local = (int)(b - k.first_block);
+    const int per_tap = k.tiles_g * k.tiles_d;
+    const int t = local / per_tap, rem = local - t * per_tap;
+    const int gy = rem / k.tiles_d, dx = rem - gy * k.tiles_d;
+    weight_prep_tile<T>(k.w, k.Cg, k.Cd, (T*)k.wn, k.wn_rows, k.wn_cols, (T*)k.wt, k.wt_rows, k.wt_cols, t, gy * 32, dx * 32, tile);
+}
+
+extern "C" long long p2p_weight_prep_task_blocks(int Cg, int Cd, int wn_rows, int wn_cols, int wt_rows, int wt_cols,
+                                                 int have_wn, int have_wt, int* tiles_g, int* tiles_d) {
+    int gmax = Cg, dmax = Cd;
+    if (have_wn) { gmax = gmax > wn_rows ? gmax : wn_rows; dmax = dmax > wn_cols ? dmax : wn_cols; }
+    if (have_wt) { gmax = gmax > wt_cols ? gmax : wt_cols; dmax = dmax > wt_rows ? dmax : wt_rows; }
+    const int tg = (gmax + 31) / 32, td = (dmax + 31) / 32;
+    if (tiles_g) *tiles_g = tg;
+    if (tiles_d) *tiles_d = td;
+    return 16LL * tg * td;
+}
+
+extern "C" int p2p_weight_prep_batched(int dtype, const p2p_prep_task* tasks_dev, int ntasks, long long total_blocks, void* stream) {
+    P2P_REQUIRE(tasks_dev && ntasks >= 1 && ntasks <= 64 && total_blocks >= 1 && total_blocks < (1LL << 31),
+                "p2p_weight_prep_batched: bad args");
+    P2P_DISPATCH_DTYPE(dtype, (weight_prep_batched_kernel<T><<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>(tasks_dev, ntasks)));
+    return p2p_check_launch("p2p_weight_prep_batched");
 }
 
 extern "C" int p2p_weight_prep_pad(int dtype, const float* w, int Cg, int Cd, void* wn, int wn_rows, int wn_cols,

@@ -263,6 +263,7 @@ class Pix2PixEngine:
         self.use_conv_edge = os.environ.get("P2P_CONV_EDGE", "0") != "0"
         self.use_conv_fewout = os.environ.get("P2P_CONV_FEWOUT", "1") != "0"    # 1..4-output heads: tap-major GEMM + shifted sum
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
+        self._prep_table = None
         self.refresh_weight_copies()
 
     # ------------------------------------------------------------------ parameters
@@ -308,16 +309,43 @@ class Pix2PixEngine:
                     lw.wd = torch.zeros(16 * cg * cd, dtype=tdt, device=dev)
                 self.W[(sid, name)] = lw
 
-    def refresh_weight_copies(self):
-        """Re-derives the per-layer weight copies from the f32 masters; runs after every Adam step."""
+    def _prep_tasks(self):
+        """Device table of p2p_prep_task descriptors (one per weight copy set); the pointers are stable for the life
+        of the engine, so it is built once."""
+        if self._prep_table is not None:
+            return self._prep_table
+        specs = []
         for (sid, name), lw in self.W.items():
             master = self._store(sid).p(name + ".kernel")
             if lw.wt is not None or lw.wn is not None:
-                L.call("p2p_weight_prep_pad", self.dtype, master, lw.cg, lw.cd,
-                       _p(lw.wn) if lw.wn is not None else NULL, up32(lw.cg), lw.lo_pad,
-                       _p(lw.wt) if lw.wt is not None else NULL, up32(lw.cd), lw.hi_pad, _stream())
+                specs.append((master, lw.cg, lw.cd, lw.wn, up32(lw.cg), lw.lo_pad, lw.wt, up32(lw.cd), lw.hi_pad))
             if lw.wd is not None:
-                L.call("p2p_weight_prep_pad", self.dtype, master, lw.cg, lw.cd, _p(lw.wd), lw.cg, lw.cd, NULL, 0, 0, _stream())
+                specs.append((master, lw.cg, lw.cd, lw.wd, lw.cg, lw.cd, None, 0, 0))
+        if not specs:
+            self._prep_table = (None, 0, 0)
+            return self._prep_table
+        tasks = (L.PrepTask * len(specs))()
+        first = 0
+        for k, (master, cg, cd, wn, wn_r, wn_c, wt, wt_r, wt_c) in enumerate(specs):
+            tg, td = C.c_int(0), C.c_int(0)
+            nb = L.lib().p2p_weight_prep_task_blocks(cg, cd, wn_r, wn_c, wt_r, wt_c, int(wn is not None), int(wt is not None),
+                                                     C.byref(tg), C.byref(td))
+            t = tasks[k]
+            t.w = master.value
+            t.wn = wn.data_ptr() if wn is not None else None
+            t.wt = wt.data_ptr() if wt is not None else None
+            t.Cg, t.Cd, t.wn_rows, t.wn_cols, t.wt_rows, t.wt_cols = cg, cd, wn_r, wn_c, wt_r, wt_c
+            t.tiles_g, t.tiles_d, t.first_block = tg.value, td.value, first
+            first += nb
+        raw = torch.frombuffer(bytearray(bytes(tasks)), dtype=torch.uint8).to(self.device)
+        self._prep_table = (raw, len(specs), first)
+        return self._prep_table
+
+    def refresh_weight_copies(self):
+        """Re-derives the per-layer weight copies from the f32 masters; runs after every Adam step (one launch)."""
+        raw, ntasks, total = self._prep_tasks()
+        if ntasks:
+            L.call("p2p_weight_prep_batched", self.dtype, _p(raw), ntasks, total, _stream())
 
     def _wn(self, sid, name):
         lw = self.W[(sid, name)]
