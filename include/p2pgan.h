@@ -96,15 +96,6 @@ int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin
                    const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
                    int act, float alpha, void* stream);
 
-/* LDS-resident form of p2p_igemm_edge for the layers whose whole weight tensor fits in LDS (<= 96 KB as
- * [16][ncols up to 128][cin_pad]) and whose rows are 16..64 pixels wide: weights stay in LDS for the life of the
- * workgroup, every input strip is staged once, all taps are contracted out of LDS.  Same arguments and semantics as
- * p2p_igemm_edge; p2p_conv_edge_ok tells whether the shape is supported. */
-int p2p_conv_edge_ok(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols);
-int p2p_conv_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
-                  const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
-                  int act, float alpha, void* stream);
-
 /* Few-output form (ncols <= 4, 32 < cin_pad <= 64; op G stride 1 or op P stride 2): the generator's 36 -> 4 head, the
  * discriminator's 64 -> 1 head and d(D first conv)/d(fake image) 64 -> 4 (networks.py:46,57,75-78).  Contracts the
  * channels first (rows = 16 taps x outputs, no padding of the 1..4 outputs to a 32-row tile, every input pixel read
@@ -114,6 +105,15 @@ int p2p_conv_fewout_ok(int op, int stride, int dtype, int N, int LH, int LW, int
 int p2p_conv_fewout(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
                     const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
                     int act, float alpha, void* stream);
+
+/* Few-input form (cin_pad == 8: one 16-byte pixel, bf16 only; op G stride 1/2 or op P stride 1; ncols <= 64): the first
+ * convolution of both networks and the data gradients of the two stride-1 heads (networks.py:10-16,45-46,57,75-78).
+ * Weights live in registers, a strip of input rows in LDS, one MFMA K step = two taps, LDS-transposed 16-byte stores.
+ * Same arguments and semantics as p2p_igemm_edge; p2p_conv_fewin_ok tells whether the shape is supported. */
+int p2p_conv_fewin_ok(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols);
+int p2p_conv_fewin(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                   const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
+                   int act, float alpha, void* stream);
 
 /* MFMA weight gradient of a stride-2 block: dw[16][Cg][Cd] (f32) = sum over pixels.  The pixel sum is
  * split over `msplit` workgroups per tile; partial slabs go to `workspace`

@@ -258,10 +258,8 @@ class Pix2PixEngine:
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
-        # LDS-resident edge convolutions: measured 10-30% slower than the implicit-GEMM edge path on every c2 shape (r01),
-        # so opt-in until the kernel overlaps its strip loads with the MFMA loop
-        self.use_conv_edge = os.environ.get("P2P_CONV_EDGE", "0") != "0"
         self.use_conv_fewout = os.environ.get("P2P_CONV_FEWOUT", "1") != "0"    # 1..4-output heads: tap-major GEMM + shifted sum
+        self.use_conv_fewin = os.environ.get("P2P_CONV_FEWIN", "1") != "0"      # 8-channel inputs: weights in registers, strip in LDS
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self._prep_table = None
         self.refresh_weight_copies()
@@ -523,8 +521,8 @@ class Pix2PixEngine:
                 cin_pad, nc, rows, w = lw.lo_pad, (ncols or cg), up32(cg), self._wn(sid, name)
             if self.use_conv_fewout and L.lib().p2p_conv_fewout_ok(op, stride, self.dtype, N, lh, lh, cin_pad, nc):
                 entry = "p2p_conv_fewout"
-            elif self.use_conv_edge and L.lib().p2p_conv_edge_ok(op, stride, self.dtype, N, lh, lh, cin_pad, nc):
-                entry = "p2p_conv_edge"
+            elif self.use_conv_fewin and L.lib().p2p_conv_fewin_ok(op, stride, self.dtype, N, lh, lh, cin_pad, nc):
+                entry = "p2p_conv_fewin"
             else:
                 entry = "p2p_igemm_edge"
             L.call(entry, op, stride, self.dtype, N, lh, lh, cin_pad, nc, rows, C.byref(in_view),

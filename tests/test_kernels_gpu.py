@@ -289,12 +289,22 @@ def test_edge_layers_few_outputs(dtype, n, lh, cg, cd, stride, g_ok, p_ok):
     test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_conv_fewout")
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n,lh,cg,cd,stride", [(2, 32, 4, 64, 2), (3, 32, 8, 64, 2), (2, 64, 36, 4, 1), (2, 32, 64, 1, 1),
-                                                (2, 16, 1, 64, 2), (5, 16, 33, 8, 1)])
-def test_edge_layers_lds_resident(dtype, n, lh, cg, cd, stride):
-    """Same layers through p2p_conv_edge (weights + input strip resident in LDS)."""
-    test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_conv_edge")
+@pytest.mark.parametrize("n,lh,cg,cd,stride,g_ok,p_ok", [
+    (2, 32, 4, 64, 2, True, False),      # down1: RGBA(+4) -> 64, stride 2
+    (3, 32, 8, 64, 2, True, False),      # discriminator first conv: 8 -> 64
+    (2, 64, 36, 4, 1, False, True),      # d(generator head)/d(concat): 4(+4) -> 32 of 36, transposed stride 1
+    (3, 32, 64, 1, 1, False, True),      # d(discriminator head)/d(features): 1(+7) -> 64 (32 columns here)
+    (2, 16, 1, 64, 2, True, False),      # indexed input, 16-pixel rows: MFMA tiles straddle rows
+    (5, 8, 3, 48, 1, True, False),       # stride 1, 8-pixel rows, 48 outputs (two masked chunks)
+    (2, 8, 5, 20, 1, True, False)])      # ragged last chunk
+def test_edge_layers_few_inputs(n, lh, cg, cd, stride, g_ok, p_ok):
+    """Same layers through p2p_conv_fewin (bf16 only: weights in registers, strip in LDS, one K step = two taps)."""
+    dtype = L.BF16
+    hi_pad, lo_pad = E.pad8(cg), E.pad8(cd)
+    assert bool(L.lib().p2p_conv_fewin_ok(L.OP_G, stride, dtype, n, lh, lh, hi_pad, cd)) == g_ok
+    assert bool(L.lib().p2p_conv_fewin_ok(L.OP_P, stride, dtype, n, lh, lh, lo_pad, min(cg, 32))) == p_ok
+    assert not L.lib().p2p_conv_fewin_ok(L.OP_G, stride, L.F32, n, lh, lh, hi_pad, cd)
+    test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_conv_fewin")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
