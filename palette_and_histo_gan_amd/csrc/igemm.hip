@@ -38,7 +38,6 @@ struct IgemmArgs {
     // fused InstanceNorm statistics (VEPI epilogue): per (image, slot, channel) the mean and the centred sum of squares
     // of `stat_rows` consecutive output pixels of one image; slot = phase * tiles_per_image + tile_in_image
     float* stat_part; int stat_rows; int stat_slots; int lgHW;
-    int flags;           // tuning: bit 0 = spread the next K-block's LDS-DMA pieces over the four k-steps, bit 1 = s_setprio around MFMAs
 };
 
 template <typename T> struct Frag;
@@ -59,10 +58,12 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 }
 
 template <typename T, int WM, int WN, int TM, int TN, bool GEN, bool VEPI, int NST>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
+    constexpr int NW = WM * WN, NTHR = NW * 64;     // waves / threads per workgroup (4 or 8 waves)
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = BM / 32, NB = BN / 32;       // rows staged per thread
+    constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW);       // 8-row pieces (1 KB per wave-instruction) staged per thread
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave stages the same number of pieces (counted vmcnt)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     int aq[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        int r = (i * 4 + wave) * 8 + (lane >> 3);
+        int r = (i * NW + wave) * 8 + (lane >> 3);
         int m = min(m0 + r, a.M - 1);
         int x = m & (a.LW - 1);
         int y = (m >> a.lgLW) & (a.LH - 1);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     int bbase[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        int r = (j * 4 + wave) * 8 + (lane >> 3);
+        int r = (j * NW + wave) * 8 + (lane >> 3);
         bq[j] = (lane & 7) ^ ((r >> 1) & 7);
         bbase[j] = (n0 + r) * a.C * esz;
     }
@@ -133,12 +134,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         if (p < NA) {
             split_k(kb, aq[p], tl, cbyte);
             tap_geom(tl, dy, dx, widx);
-            glds16(abase[p] + (dy * rowB + dx * pixB + cbyte), buf + (p * 4 + wave) * 1024);
+            glds16(abase[p] + (dy * rowB + dx * pixB + cbyte), buf + (p * NW + wave) * 1024);
         } else {
             const int j = p - NA;
             split_k(kb, bq[j], tl, cbyte);
             tap_geom(tl, dy, dx, widx);
-            glds16(a.w + (widx * wtap + bbase[j] + cbyte), buf + A_BYTES + (j * 4 + wave) * 1024);
+            glds16(a.w + (widx * wtap + bbase[j] + cbyte), buf + A_BYTES + (j * NW + wave) * 1024);
         }
     };
     auto stage = [&](int kb, char* buf) {
@@ -170,7 +171,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     // NST = 3: ring of three LDS stages, two K-blocks of loads in flight across the barrier: a counted s_waitcnt leaves
     //          the younger stage's LDS-DMA outstanding (cdna_hip_programming.md "Pipelining across barriers") -- for
     //          launches that put a single workgroup on each CU.
-    const bool ilv = a.flags & 1, prio = a.flags & 2;
     stage(0, smem);
     if (NST == 3 && nkb > 1) stage(1, smem + STAGE);
     for (int kb = 0; kb < nkb; ++kb) {
@@ -186,13 +186,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         char* cur = smem + (NST == 3 ? (kb % 3) : (kb & 1)) * STAGE;
         const int kn = NST == 3 ? kb + 2 : kb + 1;                   // K-block to prefetch
         char* nxt = smem + (NST == 3 ? (kn % 3) : (kn & 1)) * STAGE;
-        if (!ilv && kn < nkb) stage(kn, nxt);
+        if (kn < nkb) stage(kn, nxt);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (ilv && kn < nkb) {
-#pragma unroll
-                for (int p = (s * NL) / 4; p < ((s + 1) * NL) / 4; ++p) stage_piece(kn, nxt, p);
-            }
             frag_t af[TM], bf[TN];
             const int q = 2 * s + h;
 #pragma unroll
@@ -201,12 +197,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[j] = *(const frag_t*)(cur + A_BYTES + brow[j] * 128 + ((q ^ ((brow[j] >> 1) & 7)) << 4));
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);       // MFMA issue ahead of the partner wave's loads (+1 % measured, r01)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mfma_step(acc[i][j], bf[j], af[i]);
-            if (prio) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -229,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             constexpr int osz = sizeof(TO);
             constexpr int RS = BN * osz + 16;     // padded row stride (16-byte aligned rows; the 32 pixel lanes' 4-channel writes hit distinct banks)
             typedef __attribute__((__vector_size__(4 * sizeof(TO)))) TO vec4_t;
-            constexpr int CE = 16 / osz, CPR = BN / CE, RPP = 256 / CPR;
+            constexpr int CE = 16 / osz, CPR = BN / CE, RPP = NTHR / CPR;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 int ml = (wm * TM + i) * 32 + (lane & 31);
@@ -257,7 +253,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             if (a.stat_part && !to_slabs) {
                 // InstanceNorm statistics of this tile (networks.py:18,29), taken from the ROUNDED values the consumer
                 // will read back: two passes over the LDS tile (mean, then centred squares), per group of stat_rows rows.
-                constexpr int NP = 256 / BN;                       // row parts per column
+                constexpr int NP = NTHR / BN;                      // row parts per column
                 float* scr = (float*)(smem + BM * RS);             // [NP][BN] scratch behind the tile
                 const int colL = tid % BN, part = tid / BN;
                 const int rows = a.stat_rows, ngrp = BM / rows;
@@ -345,8 +341,19 @@ static int igemm_env(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-static int igemm_flags() { static int v = -1; if (v < 0) v = igemm_env("P2P_IGEMM_FLAGS", 0); return v; }
-static int igemm_big() { static int v = -1; if (v < 0) v = igemm_env("P2P_IGEMM_BIG", 0); return v; }
+// minimum number of 256x128 workgroups for the 8-wave tile (0 = never): one per CU
+static int igemm_big() { static int v = -1; if (v < 0) v = igemm_env("P2P_IGEMM_BIG", 256); return v; }
+
+// Row-tile height of the launch: 128-column layers take the 8-wave 256x128 tile (three LDS stages, one workgroup per
+// CU) once that still yields igemm_big() workgroups, else the 4-wave 128x128 tile; narrower layers take 256 rows when the
+// pixel count fills the chip.  Shared by the launcher and p2p_igemm_stat_slots.
+static int igemm_bm(long long M, int ctiles, unsigned gz) {
+    if (ctiles % 128 == 0) {
+        if (igemm_big() > 0 && ((M + 255) / 256) * (ctiles / 128) * (long long)gz >= igemm_big()) return 256;
+        return 128;
+    }
+    return M >= 256 * 512 ? 256 : 128;
+}
 
 static int igemm_stage_override() {
     static int v = -1;
@@ -356,14 +363,14 @@ static int igemm_stage_override() {
 
 template <typename T, int WM, int WN, int TM, int TN, bool GEN>
 static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
     const int ctiles = (a.ncols + 31) / 32 * 32;
     dim3 grid((a.M + BM - 1) / BM, (ctiles + BN - 1) / BN, gz);
     // three LDS stages when the launch cannot put two workgroups on every CU anyway (<= 320 workgroups) and the
     // K loop is long enough to fill the ring
     const long long nblk = (long long)grid.x * grid.y * grid.z;
     const int nkb_host = (a.taps_per * a.C * (int)sizeof(T)) >> 7;
-    int nst = (nblk <= 320 && nkb_host >= 4) ? 3 : 2;
+    int nst = ((nblk <= 320 || NTHR == 512) && nkb_host >= 4) ? 3 : 2;   // 8-wave tiles: one workgroup per CU by design
     if (igemm_stage_override() == 2 || igemm_stage_override() == 3) nst = igemm_stage_override();
     if (3 * (size_t)(BM + BN) * 128 > 150 * 1024) nst = 2;
     size_t stage = (size_t)nst * (BM + BN) * 128;
@@ -378,11 +385,11 @@ static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
         attr_done = true;
     }
     if (nst == 3) {
-        if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true, 3><<<grid, dim3(256), shm, st>>>(a);
-        else igemm_kernel<T, WM, WN, TM, TN, GEN, false, 3><<<grid, dim3(256), shm, st>>>(a);
+        if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true, 3><<<grid, dim3(NTHR), shm, st>>>(a);
+        else igemm_kernel<T, WM, WN, TM, TN, GEN, false, 3><<<grid, dim3(NTHR), shm, st>>>(a);
     } else {
-        if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true, 2><<<grid, dim3(256), shm, st>>>(a);
-        else igemm_kernel<T, WM, WN, TM, TN, GEN, false, 2><<<grid, dim3(256), shm, st>>>(a);
+        if (vepi) igemm_kernel<T, WM, WN, TM, TN, GEN, true, 2><<<grid, dim3(NTHR), shm, st>>>(a);
+        else igemm_kernel<T, WM, WN, TM, TN, GEN, false, 2><<<grid, dim3(NTHR), shm, st>>>(a);
     }
 }
 
@@ -391,9 +398,7 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
     unsigned gz = (unsigned)(phases * a.splitk);
     const int ctiles = (a.ncols + 31) / 32 * 32;      // launched columns (<= w_rows)
     const bool bigM = a.M >= 256 * 512;                // enough rows to fill the chip with 256-row tiles
-    a.flags = igemm_flags();
-    if (ctiles % 128 == 0 && igemm_big() && !a.stat_part && (long long)((a.M + 255) / 256) * (ctiles / 128) * gz >= igemm_big())
-        igemm_go<T, 2, 2, 4, 2, GEN>(a, gz, vepi, st);
+    if (igemm_bm(a.M, ctiles, gz) == 256 && ctiles % 128 == 0) igemm_go<T, 4, 2, 2, 2, GEN>(a, gz, vepi, st);
     else if (ctiles % 128 == 0) igemm_go<T, 2, 2, 2, 2, GEN>(a, gz, vepi, st);
     else if (ctiles % 64 == 0) {
         if (bigM) igemm_go<T, 4, 1, 2, 2, GEN>(a, gz, vepi, st);
@@ -459,7 +464,7 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
         const int slots = p2p_igemm_stat_slots(op, N, LH, LW, ncols);
         P2P_REQUIRE(slots > 0 && vepi && splitk == 1, "p2p_igemm: fused statistics not available for this shape (query p2p_igemm_stat_slots)");
         const int ctl = (ncols + 31) / 32 * 32;
-        const int bm = (ctl % 128 == 0) ? 128 : ((long long)N * LH * LW >= 256 * 512 ? 256 : 128);
+        const int bm = igemm_bm((long long)N * LH * LW, ctl, (unsigned)phases);
         const int hw = LH * LW;
         a.stat_part = stat_part;
         a.stat_rows = hw < bm ? hw : bm;
@@ -474,7 +479,8 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
 extern "C" int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols) {
     const long long M = (long long)N * LH * LW;
     const int ctl = (ncols + 31) / 32 * 32;
-    const int bm = (ctl % 128 == 0) ? 128 : (M >= 256 * 512 ? 256 : 128);
+    const int phases_q = op == P2P_OP_P ? 4 : 1;
+    const int bm = igemm_bm(M, ctl, (unsigned)phases_q);
     const int hw = LH * LW;
     if (M % bm != 0) return 0;
     if (!(hw % bm == 0 || bm % hw == 0)) return 0;

@@ -199,23 +199,6 @@ static int ws_sum_split(int nslabs, int n) {
     return split;
 }
 
-#include <stdlib.h>
-static size_t ws_lds_cap() {
-    static long v = -1;
-    if (v < 0) { const char* e = getenv("P2P_WS_LDS_KB"); v = e ? atol(e) : 150; if (v < 16 || v > 150) v = 150; }
-    return (size_t)v * 1024;
-}
-static long long ws_slab_cap_bytes() {
-    static long v = -1;
-    if (v < 0) { const char* e = getenv("P2P_WS_SLAB_MB"); v = e ? atol(e) : 64; if (v < 1 || v > 64) v = 64; }
-    return (long long)v << 20;
-}
-static long long ws_blocks_want() {
-    static long v = -1;
-    if (v < 0) { const char* e = getenv("P2P_WS_BLOCKS"); v = e ? atol(e) : 512; if (v < 32 || v > 4096) v = 512; }
-    return v;
-}
-
 // Tiling of the LDS-resident form: 32x32 MFMA tiles per workgroup (GT x DT <= 4), channel windows, strip height.
 struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks; size_t shm; };
 
@@ -242,14 +225,14 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
         const size_t hi_bytes = (size_t)(stride * TH + 3) * (stride * LW + 3) * hpB;
         const size_t lo_bytes = (size_t)TH * LW * lpB;
         p.shm = ((hi_bytes + 15) & ~(size_t)15) + 256 + lo_bytes + 512;
-        if (p.shm <= ws_lds_cap()) break;
+        if (p.shm <= 150 * 1024) break;
         if (TH == 1) return p;
     }
     p.TH = TH;
     long long strips = (long long)N * (LH / TH);
-    long long want = ws_blocks_want() / (p.gwins * p.dwins);
+    long long want = 512 / (p.gwins * p.dwins);
     const long long slab_bytes = 16LL * Cg * Cd * 4;
-    const long long cap = ws_slab_cap_bytes() / slab_bytes;   // keep the partial slabs within 64 MB
+    const long long cap = (64LL << 20) / slab_bytes;         // keep the partial slabs within 64 MB
     if (want > cap) want = cap;
     if (want < 32) want = 32;
     p.blocks = (int)(strips < want ? strips : want);
