@@ -470,6 +470,165 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small maps (dispatched for H*W <= 16: the 1x1 ... 4x4 layers of the U-Net bottom; 8x8 measured faster on the workgroup form).  One workgroup per (image, 64 channels) leaves
+// most lanes idle there and spends its time in barriers.  Here G = min(16, H*W) lanes own one (image, VN-channel
+// vector): each lane keeps its <= 4 pixels in registers, the statistics are exact two-pass sums combined with wave
+// shuffles inside the lane group (no LDS, no barrier), and the result is written in the same pass.
+template <typename T, int PPL>
+__global__ __launch_bounds__(256) void norm_act_fwd_small(int HW, int W, int C, int lgG, long long items, const void* __restrict__ raw,
+                                                          int raw_kind, int nslabs, long long slab, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, int act, float alpha,
+                                                          const unsigned char* __restrict__ mask, TView out,
+                                                          T* __restrict__ raw_out, float* __restrict__ stats) {
+    constexpr int VN = VecOf<T>::N;
+    const int G = 1 << lgG;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long item = gid >> lgG;
+    const int g = (int)(gid & (G - 1));
+    if (item >= items) return;                       // whole lane groups leave together (G divides 64)
+    const int cvn = C / VN;
+    const int n = (int)(item / cvn), c = (int)(item - (long long)n * cvn) * VN;
+    const long long base = (long long)n * HW * C + c;
+    float x[PPL][VN];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = g + i * G;
+        if (p < HW) raw_vload<T>(raw, raw_kind, nslabs, slab, base + (long long)p * C, x[i]);
+        else {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) x[i][k] = 0.f;
+        }
+    }
+    float mu[VN], rs[VN];
+    if (gamma) {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) s += x[i][k];               // absent pixels hold 0
+            for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            mu[k] = s / (float)HW;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                const float d = (g + i * G < HW) ? x[i][k] - mu[k] : 0.f;
+                q += d * d;
+            }
+            for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            rs[k] = rsqrtf(q / (float)HW + eps);
+            if (g == 0) {
+                stats[((long long)n * C + c + k) * 2 + 0] = mu[k];
+                stats[((long long)n * C + c + k) * 2 + 1] = rs[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = g + i * G;
+        if (p >= HW) continue;
+        const long long e = base + (long long)p * C;
+        float keep[VN], y[VN];
+        if (raw_out) vstore<T>(raw_out + e, x[i]);
+        if (mask) mask_vload8(mask + e, keep, VN);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float v = gamma ? (x[i][k] - mu[k]) * rs[k] * gamma[c + k] + beta[c + k] : x[i][k];
+            if (mask) v *= keep[k];
+            if (act == P2P_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+            else if (act == P2P_ACT_RELU) v = v > 0.f ? v : 0.f;
+            y[k] = v;
+        }
+        const int yy = p / W, xx = p - yy * W;
+        vstore<T>((T*)out.ptr + out.off(n, yy, xx) + c, y);
+    }
+}
+
+template <typename T, int PPL>
+__global__ __launch_bounds__(256) void norm_act_bwd_small(int HW, int W, int C, int lgG, long long items, const T* __restrict__ raw,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int act, float alpha,
+                                                          const unsigned char* __restrict__ mask, GSrc g1, GSrc g2, TView draw,
+                                                          float* __restrict__ dgamma_part, float* __restrict__ dbeta_part) {
+    constexpr int VN = VecOf<T>::N;
+    const int G = 1 << lgG;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long item = gid >> lgG;
+    const int g = (int)(gid & (G - 1));
+    if (item >= items) return;
+    const int cvn = C / VN;
+    const int n = (int)(item / cvn), c = (int)(item - (long long)n * cvn) * VN;
+    const long long pix0 = (long long)n * HW, base = pix0 * C + c;
+    float mu[VN], rs[VN], ga[VN], be[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        mu[k] = stats[((long long)n * C + c + k) * 2 + 0];
+        rs[k] = stats[((long long)n * C + c + k) * 2 + 1];
+        ga[k] = gamma[c + k];
+        be[k] = beta[c + k];
+    }
+    float d[PPL][VN], xh[PPL][VN];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = g + i * G;
+        if (p < HW) {
+            const long long e = base + (long long)p * C;
+            float x[VN], a1[VN], a2[VN], keep[VN];
+            vload<T>(raw + e, x);
+            gsrc_vload<T>(g1, pix0 + p, c, a1);
+            gsrc_vload<T>(g2, pix0 + p, c, a2);
+            if (mask) mask_vload8(mask + e, keep, VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                xh[i][k] = (x[k] - mu[k]) * rs[k];
+                float a = xh[i][k] * ga[k] + be[k];
+                const float kp = mask ? keep[k] : 1.f;
+                a *= kp;
+                float slope = 1.f;
+                if (act == P2P_ACT_LEAKY) slope = a > 0.f ? 1.f : alpha;
+                else if (act == P2P_ACT_RELU) slope = a > 0.f ? 1.f : 0.f;
+                d[i][k] = (a1[k] + a2[k]) * slope * kp;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { d[i][k] = 0.f; xh[i][k] = 0.f; }
+        }
+    }
+    float m1[VN], m2[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) { t1 += d[i][k]; t2 += d[i][k] * xh[i][k]; }
+        for (int o = G >> 1; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+        if (g == 0) {
+            dbeta_part[(long long)n * C + c + k] = t1;
+            dgamma_part[(long long)n * C + c + k] = t2;
+        }
+        m1[k] = t1 / (float)HW;
+        m2[k] = t2 / (float)HW;
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = g + i * G;
+        if (p >= HW) continue;
+        float r[VN];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) r[k] = ga[k] * rs[k] * (d[i][k] - m1[k] - xh[i][k] * m2[k]);
+        const int yy = p / W, xx = p - yy * W;
+        vstore<T>((T*)draw.ptr + draw.off(n, yy, xx) + c, r);
+    }
+}
+
+// lane-group geometry of the small-map kernels: G = 2^lgG lanes per item, PPL pixels per lane
+static inline void small_geom(int HW, int& lgG, int& ppl) {
+    lgG = 0;
+    while ((1 << lgG) < HW && lgG < 4) ++lgG;
+    const int G = 1 << lgG;
+    const int need = (HW + G - 1) / G;
+    ppl = need <= 1 ? 1 : (need <= 2 ? 2 : 4);
+}
+
 // Batched column sums: task t reduces part[off_t .. off_t + rows*cols) (dense [rows][cols]) over rows into
 // out[out_off_t .. + cols).  table = int32[ntasks][4] = {part_off, rows, cols, out_off} on the device.
 // One launch replaces the per-layer dgamma/dbeta reductions of a whole backward pass.
@@ -600,6 +759,23 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
     const int esz = dtype == P2P_BF16 ? 2 : 4, vn = 16 / esz;
     const bool vec = C % vn == 0 && out->ld % vn == 0 && ((uintptr_t)out->ptr % 16) == 0 && ((uintptr_t)raw % 16) == 0 &&
                      (!raw_out || ((uintptr_t)raw_out % 16) == 0) && (raw_kind == 1 || slab_stride % 4 == 0) && C % 8 == 0;
+    if (vec && H * W <= 16) {
+        // small maps: lane groups with register-resident pixels (also when the conv epilogue produced statistics:
+        // recomputing them from <= 64 pixels is cheaper than pooling the slots)
+        int lgG, ppl;
+        small_geom(H * W, lgG, ppl);
+        const long long items = (long long)N * (C / vn);
+        const long long threads = items << lgG;
+        const dim3 grid((unsigned)((threads + 255) / 256));
+        hipStream_t st = (hipStream_t)stream;
+#define NF_SMALL(P_) norm_act_fwd_small<T, P_><<<grid, 256, 0, st>>>(H * W, W, C, lgG, items, raw, raw_kind, nslabs, slab_stride, gamma, \
+                                                                   beta, eps, act, alpha, mask, make_view(out), (T*)raw_out, stats)
+        if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NF_SMALL(1)); }
+        else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NF_SMALL(2)); }
+        else { P2P_DISPATCH_DTYPE(dtype, NF_SMALL(4)); }
+#undef NF_SMALL
+        return p2p_check_launch("p2p_norm_act_fwd");
+    }
     if (vec) {
         int CG = C > 64 ? 64 : C;
         while (C % CG) CG -= vn;
@@ -663,6 +839,21 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
     };
     const bool vec = gamma && C % 8 == 0 && draw->ld % vn == 0 && ((uintptr_t)draw->ptr % 16) == 0 &&
                      ((uintptr_t)raw % 16) == 0 && gs_ok(g1) && gs_ok(g2);
+    if (vec && H * W <= 16) {
+        int lgG, ppl;
+        small_geom(H * W, lgG, ppl);
+        const long long items = (long long)N * (C / vn);
+        const long long threads = items << lgG;
+        const dim3 grid((unsigned)((threads + 255) / 256));
+        hipStream_t st = (hipStream_t)stream;
+#define NB_SMALL(P_) norm_act_bwd_small<T, P_><<<grid, 256, 0, st>>>(H * W, W, C, lgG, items, (const T*)raw, stats, gamma, beta, act, alpha, \
+                                                                   mask, make_gsrc(g1), make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)
+        if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(1)); }
+        else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(2)); }
+        else { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(4)); }
+#undef NB_SMALL
+        return p2p_check_launch("p2p_norm_act_bwd");
+    }
     if (vec) {
         int CG = C > 64 ? 64 : C;
         while (C % CG) CG -= vn;
