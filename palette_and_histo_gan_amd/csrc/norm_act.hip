@@ -4,6 +4,8 @@
 // SURVEY.md 8a A13 (checked against autograd in tests/test_oracle.py).
 #include "p2p_common.hpp"
 
+typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
+
 // one workgroup = one image x CB consecutive channels; threads = (pixel lane) x (channel)
 template <typename T>
 __device__ __forceinline__ float raw_load(const void* raw, int raw_kind, int nslabs, long long slab, long long e) {
@@ -304,14 +306,20 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
                 return;
             }
         } else if (MODE == 2) {
-#pragma unroll
-            for (int k = 0; k < VN; ++k) {
-                t1[k] = 0.f; t2[k] = 0.f;
+            // add the SP split partials once per workgroup (one thread per channel, fixed order), share through LDS
+            if (threadIdx.x < CG) {
+                const int cc = cg0 + threadIdx.x;
+                float a1 = 0.f, a2 = 0.f;
                 for (int i = 0; i < SP; ++i) {
-                    t1[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 0];
-                    t2[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 1];
+                    const f32x2 v = *(const f32x2*)(ws + (((long long)n * SP + i) * C + cc) * 2);
+                    a1 += v[0]; a2 += v[1];
                 }
+                red[0][threadIdx.x] = a1;
+                red[1][threadIdx.x] = a2;
             }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { t1[k] = red[0][vid * VN + k]; t2[k] = red[1][vid * VN + k]; }
         } else {
             // MODE 3: `ws` holds the conv epilogue's per-slot (mean, centred sum of squares) of equal-sized pixel groups
             // (p2p_igemm stat_part, nslots groups per image): pooled mean and variance by the parallel-variance rule,
@@ -441,14 +449,19 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
             return;
         }
     } else {
-#pragma unroll
-        for (int k = 0; k < VN; ++k) {
-            t1[k] = 0.f; t2[k] = 0.f;
+        if (threadIdx.x < CG) {
+            const int cc = cg0 + threadIdx.x;
+            float a1 = 0.f, a2 = 0.f;
             for (int i = 0; i < SP; ++i) {
-                t1[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 0];
-                t2[k] += ws[(((long long)n * SP + i) * C + c + k) * 2 + 1];
+                const f32x2 v = *(const f32x2*)(ws + (((long long)n * SP + i) * C + cc) * 2);
+                a1 += v[0]; a2 += v[1];
             }
+            red[0][threadIdx.x] = a1;
+            red[1][threadIdx.x] = a2;
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { t1[k] = red[0][vid * VN + k]; t2[k] = red[1][vid * VN + k]; }
     }
     float m1[VN], m2[VN];
 #pragma unroll

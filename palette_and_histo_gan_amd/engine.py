@@ -581,12 +581,12 @@ class Pix2PixEngine:
     def _nsplit(self, N, res, c, bwd=False):
         """Pixel-range splits of the InstanceNorm kernels.  Measured on MI355X (B=256): the split form re-reads the
         image from HBM in its second launch, where the one-launch form re-reads it from L2, so it only pays for the
-        backward kernel (three input streams) when there would be fewer than ~512 workgroups."""
+        backward kernel (three input streams) when there would be fewer than ~1024 workgroups (4 per CU)."""
         if not bwd:
             return 1
         groups = max(1, c // 64)
         sp = 1
-        while N * groups * sp < 512 and res * res // (sp * 2) >= 64 and sp < 16:
+        while N * groups * sp < 1024 and res * res // (sp * 2) >= 64 and sp < 16:
             sp *= 2
         return sp
 
