@@ -96,6 +96,17 @@ int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin
                    const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
                    int act, float alpha, void* stream);
 
+/* LDS-strip form of p2p_igemm for the widest-map block (Cg == 32, Cd == 128, bf16: up6 forward = op P, its data gradient
+ * = op G; networks.py:26-27,66-73): the input strip is staged once, the weights live in registers, the four waves split
+ * the phases (op P) or the output channels (op G); persistent workgroups prefetch the next strip into registers.  Same
+ * tensors and weight copies as p2p_igemm (wn for op P, wt for op G), no split-K.  op P optionally writes InstanceNorm
+ * statistics like p2p_igemm: stat_part [N][slots][32][2] with slots = p2p_conv_strip_stat_slots (0 = not available).
+ * p2p_conv_strip_ok tells whether the shape is supported. */
+int p2p_conv_strip_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+int p2p_conv_strip_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+int p2p_conv_strip(int op, int dtype, int N, int LH, int LW, int Cg, int Cd,
+                   const p2p_tensor* hi, const p2p_tensor* lo, const void* w, float* stat_part, void* stream);
+
 /* Few-output form (ncols <= 4, 32 < cin_pad <= 64; op G stride 1 or op P stride 2): the generator's 36 -> 4 head, the
  * discriminator's 64 -> 1 head and d(D first conv)/d(fake image) 64 -> 4 (networks.py:46,57,75-78).  Contracts the
  * channels first (rows = 16 taps x outputs, no padding of the 1..4 outputs to a 32-row tile, every input pixel read

@@ -31,6 +31,7 @@ SIGNATURES = {
     "p2p_conv_direct": [_i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp, _vp, _vp],
     "p2p_igemm": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp, _vp],
     "p2p_igemm_edge": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
+    "p2p_conv_strip": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp],
     "p2p_conv_fewin": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_conv_fewout": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_wgemm_edge": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
@@ -70,6 +71,8 @@ SIGNATURES = {
 SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
            "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_fewin_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
+           "p2p_conv_strip_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
+           "p2p_conv_strip_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_fewout_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgrad_small_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong),

@@ -259,6 +259,7 @@ class Pix2PixEngine:
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
         self.use_conv_fewout = os.environ.get("P2P_CONV_FEWOUT", "1") != "0"    # 1..4-output heads: tap-major GEMM + shifted sum
+        self.use_conv_strip = os.environ.get("P2P_CONV_STRIP", "1") != "0"      # up6 (32 <-> 128 channels): LDS strip, weights in registers
         self.use_conv_fewin = os.environ.get("P2P_CONV_FEWIN", "1") != "0"      # 8-channel inputs: weights in registers, strip in LDS
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self._prep_table = None
@@ -502,8 +503,15 @@ class Pix2PixEngine:
         cg, cd = lw.cg, lw.cd
         hi, lo = (in_view, out_view) if op == L.OP_G else (out_view, in_view)
         if self.use_mfma and lw.main and stride == 2 and bias is None and act == L.ACT_NONE and ncols is None:
-            sk = self._splitk(op, N, lh, cg, cd)
             w = _p(lw.wt) if op == L.OP_G else self._wn(sid, name)
+            if self.use_conv_strip and L.lib().p2p_conv_strip_ok(op, self.dtype, N, lh, lh, cg, cd):
+                slots = L.lib().p2p_conv_strip_stat_slots(op, self.dtype, N, lh, lh, cg, cd) if want_stats else 0
+                if N * slots * cg * 2 > P["spart"].numel():
+                    slots = 0
+                L.call("p2p_conv_strip", op, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), w,
+                       _p(P["spart"]) if slots else NULL, _stream())
+                return (1, 1, slots) if slots else (1, 1)
+            sk = self._splitk(op, N, lh, cg, cd)
             slots = 0
             if want_stats and sk == 1:      # InstanceNorm statistics fused into the GEMM epilogue
                 slots = L.lib().p2p_igemm_stat_slots(op, N, lh, lh, cd if op == L.OP_G else cg)

@@ -96,6 +96,53 @@ def test_igemm_ops_G_and_P(dtype, n, lh, cg, cd, splitk):
         assert U.rel_err(got, ref) < tol, (op, sk)
 
 
+@pytest.mark.parametrize("n,lh", [(2, 32), (3, 64), (5, 4), (300, 8)])
+def test_conv_strip_up6(n, lh):
+    """up6 (32 <-> 128 channels) through p2p_conv_strip (LDS strip, weights in registers), forward and data gradient,
+    against the oracle and bit-for-bit-level close to p2p_igemm on the same operands."""
+    dtype, cg, cd = L.BF16, 32, 128
+    lw = lh if lh >= 32 else 32            # rows must be >= 32 pixels wide
+    rng = np.random.default_rng(21)
+    hi = U.q(rng.normal(size=(n, 2 * lh, 2 * lw, cg)), dtype)
+    lo = U.q(rng.normal(size=(n, lh, lw, cd)), dtype)
+    w = U.q(rng.normal(scale=0.05, size=(4, 4, cg, cd)), dtype)
+    hi_t, lo_t, w_t = (torch.tensor(v, dtype=F64) for v in (hi, lo, w))
+    g_ref = rg.conv4x4_s2(hi_t, w_t).numpy()
+    p_ref = rg.convT4x4_s2(lo_t, w_t).numpy()
+    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
+    wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    w_d = U.dev(w.reshape(-1))
+    L.call("p2p_weight_prep", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
+    assert not L.lib().p2p_conv_strip_ok(L.OP_P, L.F32, n, lh, lw, cg, cd)
+    assert not L.lib().p2p_conv_strip_ok(L.OP_P, dtype, n, lh, lw, 64, cd)
+    for op, ref, shape in ((L.OP_G, g_ref, (n, lh, lw, cd)), (L.OP_P, p_ref, (n, 2 * lh, 2 * lw, cg))):
+        assert L.lib().p2p_conv_strip_ok(op, dtype, n, lh, lw, cg, cd)
+        out = E.DenseBuf(*shape, U.tdt(dtype), U.DEV)
+        out.t.fill_(float("nan"))
+        hv, lv = (hi_b.view(), out.view()) if op == L.OP_G else (out.view(), lo_b.view())
+        slots = L.lib().p2p_conv_strip_stat_slots(op, dtype, n, lh, lw, cg, cd)
+        assert (slots > 0) == (op == L.OP_P)
+        spart = torch.full((max(n * slots * cg * 2, 4),), float("nan"), dtype=torch.float32, device=U.DEV)
+        L.call("p2p_conv_strip", op, dtype, n, lh, lw, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn),
+               U.ptr(spart) if slots else None, U.stream())
+        got = U.dense_to_np(out)
+        assert U.rel_err(got, ref) < OUT_TOL[dtype], op
+        if slots:       # pooled slot statistics == per-(image, channel) mean / variance of the stored (rounded) output
+            sp = spart.view(n, slots, cg, 2).cpu().numpy().astype(np.float64)
+            cnt = got.shape[1] * got.shape[2] / slots
+            mean = sp[..., 0].mean(axis=1)
+            m2 = (sp[..., 1] + cnt * (sp[..., 0] - mean[:, None, :]) ** 2).sum(axis=1)
+            g64 = got.astype(np.float64)
+            np.testing.assert_allclose(mean, g64.mean(axis=(1, 2)), atol=2e-5 * np.abs(g64).max())
+            np.testing.assert_allclose(m2 / (cnt * slots), g64.var(axis=(1, 2)), rtol=2e-4)
+        out2 = E.DenseBuf(*shape, U.tdt(dtype), U.DEV)
+        hv, lv = (hi_b.view(), out2.view()) if op == L.OP_G else (out2.view(), lo_b.view())
+        L.call("p2p_igemm", op, dtype, n, lh, lw, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn), 1, None, None,
+               U.stream())
+        assert U.rel_err(got, U.dense_to_np(out2)) < 1e-2 * OUT_TOL[dtype] + 4e-3, op     # same products, different f32 summation order
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,msplit", [(2, 4, 32, 128, 1), (2, 8, 64, 128, 2), (3, 4, 128, 256, 1), (1, 1, 128, 128, 1),
                                                 (2, 16, 32, 128, 4), (5, 2, 64, 256, 1)])
