@@ -38,7 +38,7 @@ __device__ __forceinline__ void load_rgb01(const TView& img, int n, int p, int W
 // ---- forward: raw (unnormalised) histogram [N][3][64][64] -----------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rgbuv_hist_fwd_kernel(int H, int W, TView img, float* __restrict__ hist) {
-    constexpr int PB = 128;
+    constexpr int PB = 96;           // 48 KB of operands: three workgroups per CU = all N x 3 workgroups of B=256 resident at once
     __shared__ float As[PB][HB];     // Iy * ku   [pixel][i]
     __shared__ float Bs[PB][HB];     // kv        [pixel][j]
     __shared__ float su[PB], sv[PB], siy[PB];
@@ -151,8 +151,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView img, const float* __restrict__ gh,
                                                             float* __restrict__ dimg, long long slab) {
     constexpr int PB = 64;
-    __shared__ float G[HB][HB];        // GH[i][j]
-    __shared__ float Gt[HB][HB];       // GH[j][i] transposed copy: conflict-free MFMA operand reads for both products
+    __shared__ float G[HB][HB + 1];    // GH[i][j]; the odd row stride makes the transposed operand read (product 0) conflict-free
     __shared__ float KuT[HB][PB];      // ku[i][pixel]
     __shared__ float KvT[HB][PB];      // kv[j][pixel]
     __shared__ float su[PB], sv[PB], siy[PB], sx[PB][3];
@@ -165,9 +164,7 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
     const float* g = gh + ((long long)n * 3 + c) * HB * HB;
     for (int idx = tid; idx < HB * HB; idx += 256) {
         int i = idx >> 6, j = idx & 63;
-        float v = g[idx];
-        G[i][j] = v;
-        Gt[j][i] = v;
+        G[i][j] = g[idx];
     }
     const int prod = wave >> 1;        // 0: A = GH kv (rows i), 1: Bm = GH^T ku (rows j)
     const int pt = wave & 1;           // pixel tile of 32
@@ -196,7 +193,7 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
         }
         __syncthreads();
         // D[row][col = pixel] = sum_k Lhs[row][k] * Rhs[k][pixel];  lane: row/col = lane&31, k = lane>>5
-        const float (*Lhs)[HB] = prod == 0 ? Gt : G;       // product 0 wants GH[i][k=j] = Gt[j][i]; product 1 wants GH[k=i][j] = G[i][j]
+        // product 0 wants Lhs[k = j][row = i] = GH[i][j]; product 1 wants Lhs[k = i][row = j] = GH[i][j]
         const float (*Rhs)[PB] = prod == 0 ? KvT : KuT;
         const float (*Kown)[PB] = prod == 0 ? KuT : KvT;   // the kernel row the result is paired with in the epilogue
         const float* coord = prod == 0 ? su : sv;
@@ -211,7 +208,8 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
 #pragma unroll 8
             for (int kk = 0; kk < HB / 2; ++kk) {
                 int k = 2 * kk + (lane >> 5);
-                float a = Lhs[k][rt * 32 + (lane & 31)];
+                const int row = rt * 32 + (lane & 31);
+                float a = prod == 0 ? G[row][k] : G[k][row];
                 float b = Rhs[k][pcol];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
