@@ -100,6 +100,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise P2PError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so); the library must bind to THAT instance -- the
+        # device pointers and streams it is handed come from it.  Loading torch first makes the dynamic linker resolve
+        # the library's libamdhip64 dependency to the copy that is already mapped (loaded the other way round, a second
+        # runtime is initialised and every launch fails with "no ROCm-capable device").
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
