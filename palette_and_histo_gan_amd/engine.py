@@ -495,10 +495,12 @@ class Pix2PixEngine:
 
     # ------------------------------------------------------------------ kernel wrappers
     def _conv(self, P, op, sid, name, N, lh, in_view, out_view, stride=2, ncols=None, bias=None, act=L.ACT_NONE,
-              tmp=None, want_stats=False):
+              tmp=None, want_stats=False, slab_key=None):
         """op G (gathers the hi view, writes lo) or op P (gathers the lo view, writes hi).  Returns (raw_kind,
-        nslabs): the result is in the output view in the activation dtype (1, 1) or in the f32 split-K slabs
-        P['slabs'] (2, nslabs).  `ncols` limits op P to the first ncols output channels."""
+        nslabs): the result is in the output view in the activation dtype (1, 1) or in f32 split-K slabs (2, nslabs):
+        the shared workspace P['slabs'], or -- with `slab_key` -- a buffer of its own that stays valid until the same
+        layer runs again, returned as a third element (2, nslabs, tensor).  `ncols` limits op P to the first ncols
+        output channels."""
         lw = self.W[(sid, name)]
         cg, cd = lw.cg, lw.cd
         hi, lo = (in_view, out_view) if op == L.OP_G else (out_view, in_view)
@@ -517,11 +519,19 @@ class Pix2PixEngine:
                 slots = L.lib().p2p_igemm_stat_slots(op, N, lh, lh, cd if op == L.OP_G else cg)
                 if N * slots * (cd if op == L.OP_G else cg) * 2 > P["spart"].numel():
                     slots = 0
+            slabs = P["slabs"]
+            if sk > 1 and slab_key is not None:
+                need = sk * N * (lh * lh * cd if op == L.OP_G else 4 * lh * lh * cg)
+                slabs = P.setdefault("own_slabs", {}).get(slab_key)
+                if slabs is None or slabs.numel() < need:
+                    slabs = P["own_slabs"][slab_key] = torch.empty(need, dtype=torch.float32, device=self.device)
             L.call("p2p_igemm", op, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), w, sk,
-                   _p(P["slabs"]) if sk > 1 else NULL, _p(P["spart"]) if slots else NULL, _stream())
+                   _p(slabs) if sk > 1 else NULL, _p(P["spart"]) if slots else NULL, _stream())
             if slots:
                 return (1, 1, slots)
-            return (1, 1) if sk == 1 else (2, sk)
+            if sk == 1:
+                return (1, 1)
+            return (2, sk, slabs) if slab_key is not None else (2, sk)
         if self.use_mfma:
             if op == L.OP_G:
                 cin_pad, nc, rows, w = lw.hi_pad, cd, up32(cd), _p(lw.wt)
@@ -617,7 +627,8 @@ class Pix2PixEngine:
         """gradient source for a conv result that went to `buf` (kind 1) or to the split-K slabs (kind 2)."""
         if rk[0] == 1:
             return buf.gsrc(coff=coff, kind=1)
-        return L.GSrc(P["slabs"].data_ptr(), 2, rk[1], buf.n * buf.h * buf.w * buf.c, buf.c, coff)
+        slabs = rk[2] if len(rk) == 3 else P["slabs"]
+        return L.GSrc(slabs.data_ptr(), 2, rk[1], buf.n * buf.h * buf.w * buf.c, buf.c, coff)
 
     def _norm_bwd(self, P, name, N, res, c, raw_buf, stats, act, mask, g1, g2, draw_view):
         ob, og = P["part_off"][name]
@@ -772,12 +783,13 @@ class Pix2PixEngine:
                            self._gs(P, gc[i], rk_gc[i], 0), None, P["du"][i].view())
             self._wgrad(P, "G", f"up{i}", B, lh, P["du"][i].view(), lo_buf.view())
             out_buf = gc[i - 1] if i > 1 else ga[6]
-            rk = self._conv(P, L.OP_G, "G", f"up{i}", B, lh, P["du"][i].view(), out_buf.view())
-            rk = self._materialise(P, out_buf, rk)
+            # split-K results stay in f32 slabs of their own: both consumers (the norm backward of up_{i-1} now, of the
+            # skip partner down_{7-i} later) sum them on load -- no pass that only folds the slabs
+            rk = self._conv(P, L.OP_G, "G", f"up{i}", B, lh, P["du"][i].view(), out_buf.view(), slab_key=f"up{i}.dgrad")
             if i > 1:
                 rk_gc[i - 1] = rk
         # down path, last to first
-        g_from_down = ga[6].gsrc()
+        g_from_down = self._gs(P, ga[6], rk, 0)
         for i in range(6, 0, -1):
             f = DOWN_FILTERS[i - 1]
             res = S // 2 ** i
@@ -795,23 +807,13 @@ class Pix2PixEngine:
                 hi_view = P["src"].view()
             self._wgrad(P, "G", f"down{i}", B, res, hi_view, P["dd"][i].view())
             if i > 1:
-                rk = self._conv(P, L.OP_P, "G", f"down{i}", B, res, P["dd"][i].view(), ga[i - 1].view())
-                self._materialise(P, ga[i - 1], rk)
-                g_from_down = ga[i - 1].gsrc()
+                rk = self._conv(P, L.OP_P, "G", f"down{i}", B, res, P["dd"][i].view(), ga[i - 1].view(),
+                                slab_key=f"down{i}.dgrad")
+                g_from_down = self._gs(P, ga[i - 1], rk, 0)
         # dgamma/dbeta sum over batch AND space: one batched reduction of every layer's
         # per-image partials into the flat gradient buffer
         L.call("p2p_colsum_batched", _p(P["part"]), _p(P["part_tasks"]), int(P["part_tasks"].shape[0]), P["part_maxc"],
                _p(self.G.grads), _stream())
-
-    def _materialise(self, P, buf, rk):
-        """Split-K slabs are a single shared workspace: sum them into `buf` (activation dtype) right away so
-        a later conv may reuse the workspace.  (Uses the norm kernel in pass-through mode.)"""
-        if rk[0] == 1:
-            return rk
-        L.call("p2p_norm_act_fwd", self.dtype, buf.n, buf.h, buf.w, buf.c, _p(P["slabs"]), 2, rk[1],
-               buf.n * buf.h * buf.w * buf.c, NULL, NULL, IN_EPS, L.ACT_NONE, 0.0, NULL, C.byref(buf.view()),
-               NULL, NULL, NULL, 0, self._nsplit(buf.n, buf.h, buf.c), _stream())
-        return (1, 1)
 
     def _reduce_tail(self):
         """after the backward pass: the small-tensor tail of the generator gradients (gamma/beta/bias), the whole
