@@ -255,6 +255,7 @@ class Pix2PixEngine:
         # order of the loss slots, so one p2p_loss_partials_sum fills losses[0..3]; row 4 = discarded (generate())
         self.loss_part = torch.zeros(5 * 256, dtype=torch.float32, device=self.device)
         self.step_count = 0
+        self._ticked = False
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
@@ -669,6 +670,28 @@ class Pix2PixEngine:
             views += [P["dcat"].view(coff=ic), P["dcat"].view(coff=ic, n0=B)]
         self._pack_multi(P, src_t, views, ic)
 
+    def _early_side(self, P, masks, apply_update):
+        """The launches of a train step that depend on nothing but device counters -- the dropout keep-masks, the mask
+        counter and Adam's step counters / step sizes -- go to the weight-gradient stream at the start of the step, off
+        the critical path (six ~5 us kernels plus their launch gaps)."""
+        self.side.fork()
+        with self.side.run():
+            if masks is None:
+                for i, drop in enumerate(UP_DROPOUT, start=1):
+                    if drop:
+                        m = P["mask"][i]
+                        L.call("p2p_dropout_mask_dev", _p(m), m.numel(), self.seed, _p(self.mask_counter_dev), i, _stream())
+            if apply_update:
+                L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
+                for store in (self.G, self.D):
+                    L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
+                self._ticked = True
+            P["early_masks"] = masks is None
+            P["early_ev"] = None
+            if self.side.enabled:
+                P["early_ev"] = torch.cuda.Event()
+                P["early_ev"].record(torch.cuda.current_stream())
+
     def generator_forward(self, P, masks=None):
         """UnetGenerator forward up to the pre-activation head output z (networks.py:80-98)."""
         B, S = P["B"], self.S
@@ -696,6 +719,10 @@ class Pix2PixEngine:
                 mask = P["mask"][i]
                 if masks is not None:
                     mask.copy_(torch.as_tensor(masks[i - 1]).reshape(mask.shape).to(torch.uint8))
+                elif P.get("early_masks"):      # generated on the side stream at the start of the step
+                    if P.get("early_ev") is not None:
+                        torch.cuda.current_stream().wait_event(P["early_ev"])
+                        P["early_ev"] = None
                 else:       # Bernoulli(0.5) keep mask (networks.py:31-32), counter-based device RNG
                     L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self.seed, _p(self.mask_counter_dev), i, _stream())
             self._norm_fwd(P, B, 2 * lh, f, P["ru"][i], rk, self.G.p(f"up{i}.gamma"), self.G.p(f"up{i}.beta"),
@@ -703,6 +730,7 @@ class Pix2PixEngine:
             lo_view = c[i].view()
         # head: Conv2D(out, 4, stride 1, SAME, bias) (networks.py:75-78)
         self._conv(P, L.OP_G, "G", "last", B, S, c[6].view(), P["z"].view(), stride=1, bias=self.G.p("last.bias"))
+        P["early_masks"] = False
 
     def discriminator_forward(self, P, N2):
         """PatchDiscriminator on the first N2 images of dcat (networks.py:45-48)."""
@@ -739,6 +767,7 @@ class Pix2PixEngine:
         self._pack(P, real_t, P["dcat"].view(coff=0), ic)
         if lambda_hist is not None:
             self._hist_real_early(P, B)
+        self._early_side(P, masks, apply_update)
         self.generator_forward(P, masks)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
         inv_l1 = 1.0 / (Bg * S * S * self.out_ch)
@@ -812,8 +841,10 @@ class Pix2PixEngine:
                 g_from_down = self._gs(P, ga[i - 1], rk, 0)
         # dgamma/dbeta sum over batch AND space: one batched reduction of every layer's
         # per-image partials into the flat gradient buffer
-        L.call("p2p_colsum_batched", _p(P["part"]), _p(P["part_tasks"]), int(P["part_tasks"].shape[0]), P["part_maxc"],
-               _p(self.G.grads), _stream())
+        self.side.fork()
+        with self.side.run():       # only Adam reads these sums: off the critical path like the weight gradients
+            L.call("p2p_colsum_batched", _p(P["part"]), _p(P["part_tasks"]), int(P["part_tasks"].shape[0]), P["part_maxc"],
+                   _p(self.G.grads), _stream())
 
     def _reduce_tail(self):
         """after the backward pass: the small-tensor tail of the generator gradients (gamma/beta/bias), the whole
@@ -842,12 +873,15 @@ class Pix2PixEngine:
 
     def apply_adam(self):
         """Both optimizers step with gradients taken at the same pre-update weights (pix2pix_model.py:81-83)."""
+        ticked, self._ticked = self._ticked, False      # counters already advanced by _early_side of this step
         for store in (self.G, self.D):
             store.t += 1
-            L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
+            if not ticked:
+                L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
             L.call("p2p_adam_flat_dev", _p(store.params), _p(store.grads), _p(store.m), _p(store.v), store.numel,
                    _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
-        L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
+        if not ticked:
+            L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
         self.refresh_weight_copies()
 
     def _histogram_loss(self, P, B, Bg, lambda_hist, hist_allreduce):
@@ -925,6 +959,7 @@ class Pix2PixEngine:
         real_t = self._to_device(real_idx, 1, B, is_int=True)
         self._pack_source(P, src_t, with_disc=True)
         self._pack(P, real_t, P["dcat"].view(coff=0), 1)
+        self._early_side(P, masks, apply_update)
         self.generator_forward(P, masks)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
         inv_pix = 1.0 / (Bg * S * S)
