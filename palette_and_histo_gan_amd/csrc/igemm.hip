@@ -8,7 +8,7 @@
 // pixel's channels (the zero halo around every image supplies the SAME padding, so no bounds checks),
 // B rows are one output channel's weights.
 //
-// Tiling (CDNA4, wave64): 256 threads = 4 waves; block tile BM x BN, wave tile (TM x TN) 32x32 MFMA tiles,
+// Tiling (CDNA4, wave64): 4 or 8 waves; block tile BM x BN, wave tile (TM x TN) 32x32 MFMA tiles,
 // K-block = 128 bytes per row (64 bf16 / 32 f32).  A and B tiles are staged global->LDS with
 // global_load_lds_dwordx4 (no VGPR round trip); the LDS image is lane-linear, so the bank swizzle
 // (16-byte slot ^= (row>>1)&7, conflict-free for ds_read_b128 MFMA operand reads) is applied to the
@@ -399,7 +399,9 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
     const int ctiles = (a.ncols + 31) / 32 * 32;      // launched columns (<= w_rows)
     const bool bigM = a.M >= 256 * 512;                // enough rows to fill the chip with 256-row tiles
     if (igemm_bm(a.M, ctiles, gz) == 256 && ctiles % 128 == 0) igemm_go<T, 4, 2, 2, 2, GEN>(a, gz, vepi, st);
-    else if (ctiles % 128 == 0) igemm_go<T, 2, 2, 2, 2, GEN>(a, gz, vepi, st);
+    // 128x128: eight waves (32x64 each), i.e. twice the waves per SIMD for the same LDS: +12 % over four 64x64 waves
+    // (r01, A/B on one device); the 64- and 32-column tiles measured no better with eight waves and keep four
+    else if (ctiles % 128 == 0) igemm_go<T, 4, 2, 1, 2, GEN>(a, gz, vepi, st);
     else if (ctiles % 64 == 0) {
         if (bigM) igemm_go<T, 4, 1, 2, 2, GEN>(a, gz, vepi, st);
         else igemm_go<T, 2, 2, 2, 1, GEN>(a, gz, vepi, st);
