@@ -204,7 +204,12 @@ def main():
         result["conv_tflops"] = round(flops_img * value / 1e12, 2)
         result["conv_mfma_frac_of_peak"] = round(flops_img * value / 1e12 / (MFMA_PEAK[args.dtype] * world), 4)
         if not args.no_profile:
-            prof, records = kernel_profile(eng, run_step_eager)
+            # per-call device times of rank 0's LOCAL step (no collectives: the other ranks are already at the barrier)
+            def run_step_local():
+                if indexed:
+                    return eng.train_step_indexed(src_d, tgt_d, lam_l1, global_batch=B)
+                return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B)
+            prof, records = kernel_profile(eng, run_step_local)
             result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype, MFMA_PEAK[args.dtype])
             # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; reduced
@@ -217,7 +222,7 @@ def main():
                     result["roofline"]["traffic_unit"] = "bytes/launch (PMC)"
             if args.detail:
                 FL.write_detail(records, args.detail, n_steps=3)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
             result["cpu_baseline"] = cpu_baseline("baseline" if indexed else model, S, 100.0 if indexed else lam_l1, lam_hist)
         print(json.dumps(result), flush=True)
     if comm is not None:
