@@ -134,11 +134,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # rehearsal on a one-GPU box (P2P_REHEARSE=1, with P2P_DP_BACKEND=gloo): every rank shares cuda:0, the collectives go
+    # through gloo -- same bench code path as the driver's RCCL run, which needs one GPU per rank
+    rehearse = os.environ.get("P2P_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     # under torchrun (RANK set) the RCCL process group is created even for one rank, so the collective path is the
     # same code at N = 1, 2, 4, 8
-    comm = PAR.init_data_parallel(device) if (world > 1 or "RANK" in os.environ) else None
+    comm = PAR.init_data_parallel(device, os.environ.get("P2P_DP_BACKEND")) if (world > 1 or "RANK" in os.environ) else None
 
     model, B, S, lam_l1, lam_hist, palette = CONFIGS[args.config]
     if args.batch:
