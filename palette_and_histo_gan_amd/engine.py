@@ -154,7 +154,7 @@ class ParamStore:
         self.small_range = (self.small_range[0], off)
         self.numel = off
         self.params = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grads = None                     # attached by the engine (one allocation for both networks + loss slots)
         self.m = torch.zeros(off, dtype=torch.float32, device=device)
         self.v = torch.zeros(off, dtype=torch.float32, device=device)
         self.t = 0                            # Adam iteration count (host mirror of t_dev)
@@ -238,6 +238,11 @@ class Pix2PixEngine:
         self.tdt = _torch_dtype(dtype)
         self.G = ParamStore(generator_param_shapes(in_ch, out_ch), self.device)
         self.D = ParamStore(discriminator_param_shapes(in_ch), self.device)
+        # one allocation [G gradients | D gradients | 16 loss slots]: under data parallelism the generator's small-tensor
+        # tail, the whole discriminator gradient and the loss scalars leave in ONE all-reduce at the end of the step
+        self._grad_all = torch.zeros(self.G.numel + self.D.numel + 16, dtype=torch.float32, device=self.device)
+        self.G.grads = self._grad_all[:self.G.numel]
+        self.D.grads = self._grad_all[self.G.numel:self.G.numel + self.D.numel]
         self.rng = np.random.default_rng(seed)
         self.seed = int(seed)
         self.mask_counter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)    # advanced once per step on the device
@@ -250,7 +255,7 @@ class Pix2PixEngine:
         self._alloc_weight_copies()
         self.plans = {}
         self.lr, self.beta1, self.beta2, self.adam_eps = 2e-4, 0.5, 0.999, 1e-7   # pix2pix_model.py:28-29
-        self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self.losses = self._grad_all[self.G.numel + self.D.numel:]
         # per-workgroup partials of the loss kernels (include/p2pgan.h P2P_LOSS_BLOCKS): rows 0..2 BCE, row 3 L1 -- the
         # order of the loss slots, so one p2p_loss_partials_sum fills losses[0..3]; row 4 = discarded (generate())
         self.loss_part = torch.zeros(5 * 256, dtype=torch.float32, device=self.device)
@@ -852,10 +857,7 @@ class Pix2PixEngine:
         dp = self._dp
         if dp is None:
             return
-        lo_e, hi_e = self.G.small_range
-        dp.allreduce_async(self.G.grads[lo_e:hi_e])
-        dp.allreduce_async(self.D.grads)
-        dp.allreduce_async(self.losses)
+        dp.allreduce_async(self._grad_all[self.G.small_range[0]:])
         dp.wait_all()
         self._dp = None
 

@@ -11,8 +11,9 @@ sharding is derived in SURVEY.md 8e:
     extra scalar all-reduce of the local sum of squares sits between the histogram forward and backward.
 Collectives per step: all-reduce SUM of the flat generator gradient buffer (117.2 MB f32) in ~6 buckets of >= 16 MB
 that are issued asynchronously as soon as the weight-gradient kernels of a bucket have been launched (the flat buffer
-is laid out in backward completion order, engine.ParamStore) and so overlap the rest of the backward pass; then the
-small-tensor tail, the discriminator gradient buffer (36.9 KB) and the loss scalars.
+is laid out in backward completion order, engine.ParamStore) and so overlap the rest of the backward pass; then one
+all-reduce of the small-tensor tail, the discriminator gradient buffer (36.9 KB) and the loss scalars, which share an
+allocation with the generator gradients.
 """
 import os
 
