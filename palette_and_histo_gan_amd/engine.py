@@ -572,9 +572,11 @@ class Pix2PixEngine:
             dp = self._dp
             if dp is not None and sid == "G":
                 b = self.G.bucket_of[name]
-                if self.G.bucket_last_layer[b] == name:
+                if self.G.bucket_last_layer[b] == name and b != len(self.G.buckets) - 1:
                     # every kernel gradient of this bucket has been issued on this stream: all-reduce it now,
-                    # concurrently with the rest of the backward pass
+                    # concurrently with the rest of the backward pass.  The LAST bucket completes
+                    # with the last weight gradient of the step and sits right in front of the small-tensor tail: both
+                    # leave together in _reduce_tail (one collective less on the exposed end of the step)
                     lo_e, hi_e = self.G.buckets[b]
                     dp.allreduce_async(self.G.grads[lo_e:hi_e])
 
@@ -857,7 +859,8 @@ class Pix2PixEngine:
         dp = self._dp
         if dp is None:
             return
-        dp.allreduce_async(self._grad_all[self.G.small_range[0]:])
+        assert self.G.buckets[-1][1] == self.G.small_range[0]
+        dp.allreduce_async(self._grad_all[self.G.buckets[-1][0]:])
         dp.wait_all()
         self._dp = None
 
