@@ -34,6 +34,9 @@ struct IgemmArgs {
     int mode;            // 0 = G, 1 = P stride 2 (4 phases), 2 = P stride 1
     int si;              // input scale of op G (stride)
     int splitk, taps_per;
+    int live_taps;       // 1: a 1x1 low-resolution map -- only the taps that touch real pixels are contracted (op G: the 4
+                         // centre taps of the 2x2 input, op P: the one tap per sub-pixel phase); the others only ever
+                         // multiply the zero halo
     int act; float alpha;
     // fused InstanceNorm statistics (VEPI epilogue): per (image, slot, channel) the mean and the centred sum of squares
     // of `stat_rows` consecutive output pixels of one image; slot = phase * tiles_per_image + tile_in_image
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
     const int wtap = a.w_rows * a.C * esz;   // bytes per weight tap slab
 
     auto tap_geom = [&](int tl, int& dy, int& dx, int& widx) {
+        if (a.live_taps) tl = a.mode == 0 ? ((1 + (tl >> 1)) << 2) + 1 + (tl & 1) : 2 * ph + pw;
         if (a.mode == 0) { dy = tl >> 2; dx = tl & 3; widx = tl; }
         else if (a.mode == 1) {
             int kh = (1 - ph) + 2 * (tl >> 1), kw = (1 - pw) + 2 * (tl & 1);
@@ -435,7 +439,9 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
     const bool pow2 = a.lgCB >= 6 && ncols == w_rows && !bias && act == P2P_ACT_NONE;
     a.mode = op == P2P_OP_G ? 0 : (stride == 2 ? 1 : 2);
     a.si = stride;
-    const int ntaps = a.mode == 1 ? 4 : 16;
+    // a 1x1 lo map (2x2 hi map) only meets real pixels through 4 of the 16 taps (op G) / 1 of the 4 taps of a phase (op P)
+    a.live_taps = (stride == 2 && LH == 1 && LW == 1) ? 1 : 0;
+    const int ntaps = a.live_taps ? (a.mode == 1 ? 1 : 4) : (a.mode == 1 ? 4 : 16);
     P2P_REQUIRE(splitk >= 1 && ntaps % splitk == 0, "p2p_igemm: splitk=%d must divide %d", splitk, ntaps);
     a.taps_per = ntaps / splitk;
     P2P_REQUIRE(((long long)a.taps_per * C * esz) % 128 == 0, "p2p_igemm: K per split must be a multiple of 128 bytes");
@@ -484,6 +490,7 @@ extern "C" int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols) {
     const int phases_q = op == P2P_OP_P ? 4 : 1;
     const int bm = igemm_bm(M, ctl, (unsigned)phases_q);
     const int hw = LH * LW;
+    if (hw * phases_q <= 16) return 0;      // output maps of <= 16 pixels: p2p_norm_act_fwd takes its own statistics there
     if (M % bm != 0) return 0;
     if (!(hw % bm == 0 || bm % hw == 0)) return 0;
     const int phases = op == P2P_OP_P ? 4 : 1;

@@ -442,6 +442,8 @@ class Pix2PixEngine:
     # -- heuristics for the MFMA kernels --------------------------------------------------------------
     def _splitk(self, op, B, lh, cg, cd):
         ntaps = 16 if op == L.OP_G else 4
+        if lh == 1:         # 1x1 maps: p2p_igemm contracts only the taps that meet real pixels (4 / 1 per phase)
+            ntaps = 4 if op == L.OP_G else 1
         ncols = cd if op == L.OP_G else cg
         cc = cg if op == L.OP_G else cd
         esz = 2 if self.dtype == L.BF16 else 4

@@ -66,6 +66,7 @@ def test_conv_direct(dtype, n, lh, cg, cd, stride):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,splitk", [(2, 4, 64, 128, 1), (3, 8, 32, 64, 1), (2, 2, 128, 256, 2), (1, 1, 512, 512, 4),
+                                                (7, 1, 64, 128, 1), (130, 1, 128, 64, 2),
                                                 (5, 16, 32, 128, 1), (2, 4, 256, 32, 1), (2, 8, 64, 64, 2)])
 def test_igemm_ops_G_and_P(dtype, n, lh, cg, cd, splitk):
     rng = np.random.default_rng(11)
@@ -81,6 +82,8 @@ def test_igemm_ops_G_and_P(dtype, n, lh, cg, cd, splitk):
     esz = 2 if dtype == L.BF16 else 4
     for op, ref, shape in ((L.OP_G, g_ref, (n, lh, lh, cd)), (L.OP_P, p_ref, (n, 2 * lh, 2 * lh, cg))):
         ntaps = 16 if op == L.OP_G else 4
+        if lh == 1:     # 1x1 maps contract only the taps that meet real pixels
+            ntaps = 4 if op == L.OP_G else 1
         cc = cg if op == L.OP_G else cd
         sk = splitk
         while sk > 1 and (ntaps % sk or ((ntaps // sk) * cc * esz) % 128):
@@ -407,7 +410,7 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_igemm_edge
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("op,n,lh,cg,cd", [(L.OP_G, 8, 8, 64, 128), (L.OP_P, 8, 8, 64, 128), (L.OP_G, 4, 16, 32, 64),
-                                            (L.OP_P, 64, 2, 128, 256), (L.OP_P, 128, 32, 32, 128)])
+                                            (L.OP_P, 64, 4, 128, 256), (L.OP_P, 128, 32, 32, 128)])
 def test_igemm_fused_instance_norm_statistics(dtype, op, n, lh, cg, cd):
     """InstanceNorm statistics produced by the GEMM epilogue (slot partials pooled by the parallel-variance rule) and
     consumed by the apply-only norm pass == the unfused path == the oracle."""
@@ -422,6 +425,7 @@ def test_igemm_fused_instance_norm_statistics(dtype, op, n, lh, cg, cd):
     res = lh if op == L.OP_G else 2 * lh
     slots = L.lib().p2p_igemm_stat_slots(op, n, lh, lh, ncols)
     assert slots > 0
+    assert L.lib().p2p_igemm_stat_slots(L.OP_P, n, 2, 2, ncols) == 0      # <= 16-pixel output maps take their own statistics
     out = E.DenseBuf(n, res, res, ncols, U.tdt(dtype), U.DEV)
     spart = torch.full((n * slots * ncols * 2,), float("nan"), dtype=torch.float32, device=U.DEV)
     hv, lv = (hi_b.view(), out.view()) if op == L.OP_G else (out.view(), lo_b.view())
