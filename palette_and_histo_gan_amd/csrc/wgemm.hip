@@ -20,6 +20,7 @@ struct WgemmArgs {
     int Cg, Cd;             // real channel counts (store mask, output strides)
     int stride;
     int chunk;              // pixels per workgroup (multiple of BK)
+    int live_taps;          // 1: 1x1 lo map (2x2 hi map): only the 4 centre taps meet real pixels, the others write exact zeros
 };
 
 __device__ __forceinline__ void glds16w(const char* g, char* l) {
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
     const int kh = t >> 2, kw = t & 3;
     const int mbeg = bz * a.chunk;
     const int mend = min(mbeg + a.chunk, a.M);
-    const int nst = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
+    const bool dead_tap = a.live_taps && !(kh >= 1 && kh <= 2 && kw >= 1 && kw <= 2);     // sums over the zero halo only
+    const int nst = (mend > mbeg && !dead_tap) ? (mend - mbeg + BK - 1) / BK : 0;
     const int s = a.stride;
 
     auto stage = [&](int st, char* buf) {
@@ -257,6 +259,7 @@ static int wgemm_common(int dtype, int stride, int N, int LH, int LW, int Cg, in
     a.lgLW = ilog2_exact_w(LW); a.lgLH = ilog2_exact_w(LH);
     P2P_REQUIRE(a.lgLW >= 0 && a.lgLH >= 0, "p2p_wgemm: LH=%d, LW=%d must be powers of two", LH, LW);
     a.Cg = Cg; a.Cd = Cd; a.stride = stride;
+    a.live_taps = (stride == 2 && LH == 1 && LW == 1) ? 1 : 0;
     a.part = msplit == 1 ? dw : (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     int rc;
