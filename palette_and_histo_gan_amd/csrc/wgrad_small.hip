@@ -4,7 +4,7 @@
 // reduction, HBM-bound in principle.  The general kernel (wgemm.hip) re-stages the pixels once per tap; here one
 // workgroup owns a strip of output rows of one image, brings the hi strip (with its halo) and the lo strip into LDS
 // ONCE and contracts all 16 taps out of LDS: bytes from HBM = the algorithmic bytes.
-//   * 8 waves; wave w owns taps 2w, 2w+1 and all (GT x DT = 2) 32x32 MFMA tiles of them -> 4 accumulators;
+//   * 16 waves, wave w owns tap w (or 8 waves with taps 2w, 2w+1) and all GT x DT 32x32 MFMA tiles of it;
 //   * bf16: MFMA operands come from ds_read_b64_tr_b16 with PER-LANE row addresses (the 4 "rows" of a transposed
 //     read are the 4 pixels s*x+kw-1 apart in the strip, so stride-2 gathers cost nothing);
 //     f32: ds_read_b32 (one pixel per lane, v_mfma_f32_32x32x2_f32, exact);
@@ -27,8 +27,9 @@ __device__ __forceinline__ void glds16s(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T, int S, int GT, int DT>
-__global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
+template <typename T, int S, int GT, int DT, int TPW>
+__global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
+    constexpr int NTHR = 1024 / TPW;                 // TPW taps per wave: 8 waves (TPW = 2) or 16 waves (TPW = 1)
     constexpr int ESZ = sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
     char* hiL = smem;
     char* loL = smem + ((hi_bytes + 15) & ~15) + 256;           // slack: short pixels are over-read by up to 64 B
 
-    f32x16 acc[2][GT][DT];
+    f32x16 acc[TPW][GT][DT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int i = 0; i < GT; ++i)
 #pragma unroll
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
         __syncthreads();      // previous strip fully consumed
         // ---- stage the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
         const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row, hcpp = hpB >> 4;
-        for (int cI = wave * 64; cI < hchunks; cI += 512) {
+        for (int cI = wave * 64; cI < hchunks; cI += NTHR) {
             int ci = cI + lane;
             if (ci < hchunks) {
                 int rr = ci / hchunks_row, cc = ci - rr * hchunks_row;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
             }
         }
         const int lchunks_row = lrowB >> 4, lchunks = TH * lchunks_row, lcpp = lpB >> 4;
-        for (int cI = wave * 64; cI < lchunks; cI += 512) {
+        for (int cI = wave * 64; cI < lchunks; cI += NTHR) {
             int ci = cI + lane;
             if (ci < lchunks) {
                 int rr = ci / lchunks_row, cc = ci - rr * lchunks_row;
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
                         bfr[j] = u.v;
                     }
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int tap = wave * 2 + t, kh = tap >> 2, kw = tap & 3;
+                    for (int t = 0; t < TPW; ++t) {
+                        const int tap = wave * TPW + t, kh = tap >> 2, kw = tap & 3;
 #pragma unroll
                         for (int i = 0; i < GT; ++i) {
                             s16x4 r[2];
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
 #pragma unroll
                     for (int j = 0; j < DT; ++j) bfr[j] = *(const float*)(loL + (yy * TW + x) * lpB + (j * 32 + cl) * 4);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int tap = wave * 2 + t, kh = tap >> 2, kw = tap & 3;
+                    for (int t = 0; t < TPW; ++t) {
+                        const int tap = wave * TPW + t, kh = tap >> 2, kw = tap & 3;
 #pragma unroll
                         for (int i = 0; i < GT; ++i) {
                             float af = *(const float*)(hiL + ((S * yy + kh) * RW + S * x + kw) * hpB + (i * 32 + cl) * 4);
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(WsArgs a) {
     const int gwin = (hpB == hgB) ? 0 : g0, dwin = (lpB == lgB) ? 0 : d0;      // whole-pixel staging covers window 0 only
     const int h = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int tap = wave * 2 + t;
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = wave * TPW + t;
 #pragma unroll
         for (int i = 0; i < GT; ++i)
 #pragma unroll
@@ -197,6 +198,16 @@ static int ws_sum_split(int nslabs, int n) {
     int split = 1;
     while (colblocks * split < 512 && nslabs / (split * 2) >= 4 && split < 64) split *= 2;
     return split;
+}
+
+#include <stdlib.h>
+// 16 waves (one tap each) instead of 8 (two taps each): 8 % slower alone, but +1.8 % on the whole step (three A/B
+// repeats on one device, r01) -- this kernel runs on the side stream next to the data-gradient chain, where the extra
+// waves keep it issuing while the other stream's workgroups hold most of the CU
+static int ws_waves16() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("P2P_WS_W16"); v = e ? atoi(e) : 1; }
+    return v;
 }
 
 // Tiling of the LDS-resident form: 32x32 MFMA tiles per workgroup (GT x DT <= 4), channel windows, strip height.
@@ -255,10 +266,12 @@ static int ws_launch(WsArgs& a, int stride, const WsPlan& p, hipStream_t st) {
     do {                                                                                                               \
         static bool done = false;                                                                                      \
         if (!done) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)wgrad_small_kernel<T, S_, G_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)wgrad_small_kernel<T, S_, G_, D_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)wgrad_small_kernel<T, S_, G_, D_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             done = true;                                                                                               \
         }                                                                                                              \
-        wgrad_small_kernel<T, S_, G_, D_><<<grid, dim3(512), p.shm, st>>>(a);                                          \
+        if (ws_waves16()) wgrad_small_kernel<T, S_, G_, D_, 1><<<grid, dim3(1024), p.shm, st>>>(a);                    \
+        else wgrad_small_kernel<T, S_, G_, D_, 2><<<grid, dim3(512), p.shm, st>>>(a);                                  \
     } while (0)
 #define WS_SEL(S_)                                                                                                     \
     do {                                                                                                               \
