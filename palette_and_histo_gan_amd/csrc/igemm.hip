@@ -146,7 +146,31 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
             glds16(a.w + (widx * wtap + bbase[j] + cbyte), buf + A_BYTES + (j * NW + wave) * 1024);
         }
     };
+    // When a K-block (128 bytes per row) lies inside one tap (channels-per-tap bytes >= 128, all blocks but the 32-channel
+    // ones), the tap and its geometry are the same for every lane: they are derived once per K-block from wave-uniform
+    // values (scalar registers) and each piece costs one 64-bit vector add on a per-lane address that already holds the
+    // row base and the swizzled 16-byte slot.  (The per-lane form above spent ~25 vector instructions per piece.)
+    const bool uni = !GEN && a.lgCB >= 7;
+    const char* abq[NA];
+    int bbq[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) abq[i] = abase[i] + (aq[i] << 4);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bbq[j] = bbase[j] + (bq[j] << 4);
     auto stage = [&](int kb, char* buf) {
+        if (uni) {
+            const int kbyte0 = kb << 7;
+            const int tl = tap_begin + (kbyte0 >> a.lgCB), cb0 = kbyte0 & (CBbytes - 1);
+            int dy, dx, widx;
+            tap_geom(tl, dy, dx, widx);
+            const int aoff = dy * rowB + dx * pixB + cb0;
+            const char* wk = a.w + ((long long)widx * wtap + cb0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(abq[i] + aoff, buf + (i * NW + wave) * 1024);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) glds16(wk + bbq[j], buf + A_BYTES + (j * NW + wave) * 1024);
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NL; ++p) stage_piece(kb, buf, p);
     };
