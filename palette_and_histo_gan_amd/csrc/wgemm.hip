@@ -69,6 +69,8 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
     const int nst = (mend > mbeg && !dead_tap) ? (mend - mbeg + BK - 1) / BK : 0;
     const int s = a.stride;
 
+    const int hi_img32 = (int)a.hi_img, lo_img32 = (int)a.lo_img;
+    const int hi_pixB = a.hi_ld * ESZ, lo_pixB = a.lo_ld * ESZ;
     auto stage = [&](int st, char* buf) {
         const int mb = mbeg + st * BK;
 #pragma unroll
@@ -80,7 +82,10 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
             int chunk = (lg << 2) | (sl & 3);
             int m = min(mb + row, a.M - 1);                    // clamped: the lo row of m >= M is a zero halo row
             int x = m & (a.LW - 1), y = (m >> a.lgLW) & (a.LH - 1), n = m >> (a.lgLW + a.lgLH);
-            const char* src = a.hi + (((long long)n * a.hi_img + (long long)(s * y + kh - 1) * a.hi_row + (s * x + kw - 1)) * a.hi_ld + g0) * ESZ + chunk * 16;
+            // 32-bit pixel index (views of < 2^31 pixels, checked on the host), then ONE 64-bit multiply-add: the 64-bit
+            // products of the first version made the staging VALU-bound (25 % of the wave cycles, r01 SQ counters)
+            const int pix = n * hi_img32 + (s * y + kh - 1) * a.hi_row + (s * x + kw - 1);
+            const char* src = a.hi + (long long)pix * hi_pixB + (g0 * ESZ + chunk * 16);
             glds16w(src, buf + inst * 1024);
         }
 #pragma unroll
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
             const char* src;
             if (m < mend) {
                 int x = m & (a.LW - 1), y = (m >> a.lgLW) & (a.LH - 1), n = m >> (a.lgLW + a.lgLH);
-                src = a.lo + (((long long)n * a.lo_img + (long long)y * a.lo_row + x) * a.lo_ld + d0) * ESZ + chunk * 16;
+                const int pix = n * lo_img32 + y * a.lo_row + x;
+                src = a.lo + (long long)pix * lo_pixB + (d0 * ESZ + chunk * 16);
             } else {
                 src = a.lo + (((long long)(-1) * a.lo_row - 1) * a.lo_ld + d0) * ESZ + chunk * 16;   // halo row -1: zeros
             }
@@ -252,6 +258,8 @@ static int wgemm_common(int dtype, int stride, int N, int LH, int LW, int Cg, in
     const int esz = dtype == P2P_BF16 ? 2 : 4;
     P2P_REQUIRE((hi->ld * esz) % 16 == 0 && (lo->ld * esz) % 16 == 0 && ((uintptr_t)hi->ptr % 16) == 0 && ((uintptr_t)lo->ptr % 16) == 0,
                 "p2p_wgemm: pixels must be 16-byte aligned (pad the channel count of the view)");
+    P2P_REQUIRE((long long)N * hi->img_stride < (1LL << 31) && (long long)N * lo->img_stride < (1LL << 31),
+                "p2p_wgemm: views of 2^31 pixels or more are not supported");
     WgemmArgs a;
     a.hi = (const char*)hi->ptr; a.hi_img = hi->img_stride; a.hi_row = hi->row_stride; a.hi_ld = hi->ld;
     a.lo = (const char*)lo->ptr; a.lo_img = lo->img_stride; a.lo_row = lo->row_stride; a.lo_ld = lo->ld;
