@@ -80,9 +80,32 @@ __global__ __launch_bounds__(P2P_LOSS_BLOCKS) void loss_partials_sum_kernel(cons
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
+// four channels of a gradient source at pixel p (VEC path: ld % 4 == 0, coff % 4 == 0, 8/16-byte aligned base)
 template <typename T>
+__device__ __forceinline__ void gsrc_load4(const GSrc& g, long long pix, float* v) {
+    typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = 0.f;
+    if (g.kind == 0) return;
+    const long long e = pix * g.ld + g.coff;
+    if (g.kind == 1) {
+        const vec4_t q = *(const vec4_t*)((const T*)g.ptr + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = to_f32((T)q[k]);
+        return;
+    }
+    const float* p = (const float*)g.ptr + e;
+    for (int sI = 0; sI < g.nslabs; ++sI) {
+        const f32x4 q = *(const f32x4*)(p + (long long)sI * g.slab);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += q[k];
+    }
+}
+
+template <typename T, bool VEC>
 __global__ void tanh_l1_bwd_kernel(int N, PixDec dec, int C, TView fake, TView real, GSrc gd, GSrc gx,
                                    float l1_scale, TView dz) {
+    typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
     const unsigned npix = (unsigned)N * dec.H * dec.W;
     for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
         int n, y, x;
@@ -90,6 +113,22 @@ __global__ void tanh_l1_bwd_kernel(int N, PixDec dec, int C, TView fake, TView r
         const T* fp = (const T*)fake.ptr + fake.off(n, y, x);
         const T* rp = (const T*)real.ptr + real.off(n, y, x);
         T* dp = (T*)dz.ptr + dz.off(n, y, x);
+        if (VEC) {      // RGBA head: one 8/16-byte access per view
+            const vec4_t fv = *(const vec4_t*)fp, rv = *(const vec4_t*)rp;
+            float g1[4], g2[4];
+            gsrc_load4<T>(gd, p, g1);
+            gsrc_load4<T>(gx, p, g2);
+            vec4_t out;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float f = to_f32((T)fv[c]);
+                const float d = f - to_f32((T)rv[c]);
+                const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                out[c] = from_f32<T>((g1[c] + g2[c] + l1_scale * sgn) * (1.f - f * f));
+            }
+            *(vec4_t*)dp = out;
+            continue;
+        }
         for (int c = 0; c < C; ++c) {
             float f = to_f32(fp[c]);
             float d = f - to_f32(rp[c]);
@@ -150,8 +189,22 @@ extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_
     P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_tanh_l1_bwd: too many pixels");
     long long blocks = ((long long)N * H * W + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
-                                  N, PixDec::make(H, W), C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
-                                  l1_scale, make_view(dz))));
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    auto al = [&](const p2p_tensor* t) { return t->ld % 4 == 0 && ((uintptr_t)t->ptr % (4 * esz)) == 0; };
+    auto gal = [&](const p2p_gsrc* g) {
+        if (!g || !g->ptr || g->kind == 0) return true;
+        if (g->ld % 4 || g->coff % 4) return false;
+        return g->kind == 1 ? ((uintptr_t)g->ptr % (4 * esz)) == 0 : (((uintptr_t)g->ptr % 16) == 0 && g->slab_stride % 4 == 0);
+    };
+    const bool vec = C == 4 && al(fake) && al(real) && al(dz) && gal(g_d) && gal(g_extra);
+    if (vec) {
+        P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T, true><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
+                                      N, PixDec::make(H, W), C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
+                                      l1_scale, make_view(dz))));
+    } else {
+        P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T, false><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
+                                      N, PixDec::make(H, W), C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
+                                      l1_scale, make_view(dz))));
+    }
     return p2p_check_launch("p2p_tanh_l1_bwd");
 }
