@@ -66,12 +66,36 @@ class CheckpointManager:
         path = os.path.join(self.directory, f"ckpt-{len(self.saved) + 1}.pt")
         e = self.engine
         torch.save({"G": e.G.params.cpu(), "G.m": e.G.m.cpu(), "G.v": e.G.v.cpu(), "G.t": e.G.t,
-                    "D": e.D.params.cpu(), "D.m": e.D.m.cpu(), "D.v": e.D.v.cpu(), "D.t": e.D.t}, path)
+                    "D": e.D.params.cpu(), "D.m": e.D.m.cpu(), "D.v": e.D.v.cpu(), "D.t": e.D.t,
+                    "mask_counter": int(e.mask_counter_dev.item()), "step_count": e.step_count}, path)
         self.saved.append(path)
         while len(self.saved) > self.max_to_keep:
             old = self.saved.pop(0)
             if os.path.exists(old):
                 os.remove(old)
+        return path
+
+    @property
+    def latest_checkpoint(self):
+        return self.saved[-1] if self.saved else None
+
+    def restore(self, path=None):
+        """Resume: weights, both Adam states (moments and step counts) and the dropout counter, so that the next step
+        is the one that would have followed the save (tf.train.Checkpoint.restore in the reference's workflow)."""
+        path = path or self.latest_checkpoint
+        if path is None:
+            raise FileNotFoundError("no checkpoint to restore")
+        ck = torch.load(path, map_location="cpu")
+        e = self.engine
+        for store, k in ((e.G, "G"), (e.D, "D")):
+            store.params.copy_(ck[k])
+            store.m.copy_(ck[k + ".m"])
+            store.v.copy_(ck[k + ".v"])
+            store.t = int(ck[k + ".t"])
+            store.t_dev.fill_(store.t)
+        e.mask_counter_dev.fill_(int(ck.get("mask_counter", 0)))
+        e.step_count = int(ck.get("step_count", 0))
+        e.refresh_weight_copies()
         return path
 
 

@@ -39,6 +39,25 @@ def test_fit_loop_runs_like_the_notebook(tmp_path, monkeypatch):
     assert tuple(logits.shape) == (4, 32, 32, 1)
 
 
+def test_checkpoint_restore_resumes_bit_exactly(tmp_path, monkeypatch):
+    """save -> two more steps -> restore -> the same two steps: weights, Adam moments / step counts and the device
+    dropout counter all come back, so the replayed steps reproduce the first run bit for bit (f32 mode, deterministic
+    kernels: every reduction has a fixed order)."""
+    monkeypatch.chdir(tmp_path)
+    train = D.synthetic_rgba_ds(8, batch_size=4)
+    model = M.Pix2PixModel(train, train, "front2right", "pix2pix-ckpt-test", lambda_l1=100.0, dtype="f32")
+    batches = list(iter(train))
+    model.fit(2, 1)
+    path = model.checkpoint_manager.save()
+    run_a = [model.train_step(batches[i % 2], 2 + i, 1) for i in range(2)]
+    w_a = model.engine.G.params.clone()
+    assert model.checkpoint_manager.restore(path) == path and model.engine.G.t == 2
+    run_b = [model.train_step(batches[i % 2], 2 + i, 1) for i in range(2)]
+    for (ga, da), (gb, db) in zip(run_a, run_b):
+        assert all(float(x) == float(y) for x, y in zip(ga + da, gb + db))
+    assert torch.equal(w_a, model.engine.G.params)
+
+
 def test_histogram_and_indexed_models_train(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     train, test = D.synthetic_rgba_ds(8, batch_size=4, palette_size=24), D.synthetic_rgba_ds(4, batch_size=4, seed=5)
