@@ -144,6 +144,39 @@ __global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __re
     }
 }
 
+// Wide-channel form (Cd % 8 == 0, 16-byte aligned view): 16-byte loads, thread = (8-channel vector, pixel lane), a
+// workgroup covers `chunk` pixels; partial sums are combined through LDS and leave as one atomic per channel and workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void view_colsum_vec(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk) {
+    constexpr int VN = 16 / sizeof(T);
+    typedef __attribute__((__vector_size__(16))) T vec_t;
+    __shared__ float red[256 * 8];
+    const int M = N * LH * LW;
+    const int m0 = blockIdx.x * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
+    const int nvec = Cd / VN;                        // vectors per pixel (<= 256)
+    const int PL = 256 / nvec;                       // pixel lanes
+    const int cv = threadIdx.x % nvec, pl = threadIdx.x / nvec;
+    float acc[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    if (pl < PL)
+        for (int m = m0 + pl; m < m1; m += PL) {
+            const int x = m % LW, q = m / LW, y = q % LH, n = q / LH;
+            const vec_t r = *(const vec_t*)((const T*)lo.ptr + lo.off(n, y, x) + cv * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) acc[k] += to_f32((T)r[k]);
+        }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) red[threadIdx.x * VN + k] = pl < PL ? acc[k] : 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cd; c += 256) {
+        const int v = c / VN, k = c - v * VN;
+        float s2 = 0.f;
+        for (int i = 0; i < PL; ++i) s2 += red[(i * nvec + v) * VN + k];
+        atomicAdd(out + c, s2);
+    }
+}
+
 // out[d] = sum over all pixels of v[m][d]  (bias gradients of the two stride-1 heads, networks.py:47-48,75-78)
 extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && v && v->ptr && out, "p2p_view_colsum: bad args");
@@ -152,6 +185,12 @@ extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_
     if (e != hipSuccess) { p2p_set_error("p2p_view_colsum memset: %s", hipGetErrorString(e)); return (int)e; }
     long long M = (long long)N * H * W;
     P2P_REQUIRE(M < (1LL << 31), "p2p_view_colsum: too many pixels");
+    const int vn = dtype == P2P_BF16 ? 8 : 4;
+    if (C >= 64 && C % vn == 0 && C / vn <= 256 && 256 % (C / vn) == 0 && v->ld % vn == 0 && ((uintptr_t)v->ptr % 16) == 0) {
+        const int chunkv = 1024;                 // pixels per workgroup: 512 workgroups at 128 x 64 x 64
+        P2P_DISPATCH_DTYPE(dtype, (view_colsum_vec<T><<<dim3((unsigned)((M + chunkv - 1) / chunkv)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunkv)));
+        return p2p_check_launch("p2p_view_colsum");
+    }
     int chunk = C >= 64 ? 256 : 2048;            // wide pixels: few pixel lanes per workgroup -> more workgroups
     P2P_DISPATCH_DTYPE(dtype, (view_colsum<T><<<dim3((unsigned)((M + chunk - 1) / chunk)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunk)));
     return p2p_check_launch("p2p_view_colsum");

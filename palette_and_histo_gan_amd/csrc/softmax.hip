@@ -101,6 +101,92 @@ __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, i
     }
 }
 
+// 256-way fast path: 16 lanes own one pixel (16 consecutive logits each, 16-byte accesses), a wave works on 4 pixels at
+// once, every cross-lane step is a 4-level butterfly inside the 16-lane group (17 shuffles per group instead of 30 per
+// wave and pixel), pixel decode in 32-bit arithmetic.  Same arithmetic as the generic kernel: exp(z - max) / sum, argmax
+// with the lowest index on ties, -log p_t, 2 (1 - p_t).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax256_kernel(int N, PixDec dec, TView z, TView target, TView fake_idx, float grad_scale,
+                                                         float inv_count, TView dz, float* __restrict__ probs_out,
+                                                         float* __restrict__ loss_out) {
+    constexpr int VN = 16 / sizeof(T);               // elements per 16-byte access
+    typedef __attribute__((__vector_size__(16))) T vec_t;
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const unsigned M = (unsigned)N * dec.H * dec.W;
+    const unsigned gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = (gridDim.x * blockDim.x) >> 4;
+    float seg = 0.f, l1 = 0.f;
+    for (unsigned m = gid; m < M; m += ngroups) {
+        int n, y, x;
+        dec(m, n, y, x);
+        const T* zp = (const T*)z.ptr + z.off(n, y, x) + sub * 16;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16 / VN; ++q) {
+            const vec_t r = *(const vec_t*)(zp + q * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) v[q * VN + k] = to_f32((T)r[k]);
+        }
+        float mx = v[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k] = expf(v[k] - mx); sum += v[k]; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        float best = -1.f;
+        int besti = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = v[k] / sum;
+            if (v[k] > best) { best = v[k]; besti = sub * 16 + k; }      // strict '>': lowest index inside the lane
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        const int t = (int)to_f32(((const T*)target.ptr)[target.off(n, y, x)]);
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mine = (k == (t & 15)) ? v[k] : mine;
+        const float pt = __shfl(mine, (lane & 48) + ((t >> 4) & 15), 64);
+        if (sub == 0) {
+            ((T*)fake_idx.ptr)[fake_idx.off(n, y, x)] = from_f32<T>((float)besti);
+            seg += -(logf(pt));
+            l1 += 2.f * (1.f - pt);
+        }
+        if (dz.ptr) {
+            T* dp = (T*)dz.ptr + dz.off(n, y, x) + sub * 16;
+#pragma unroll
+            for (int q = 0; q < 16 / VN; ++q) {
+                vec_t r;
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    const int c = sub * 16 + q * VN + k;
+                    r[k] = from_f32<T>((v[q * VN + k] - (c == t ? 1.f : 0.f)) * grad_scale);
+                }
+                *(vec_t*)(dp + q * VN) = r;
+            }
+        }
+        if (probs_out) {
+            float* pp = probs_out + (long long)m * 256 + sub * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(pp + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+    }
+    seg = block_sum(seg, red);
+    l1 = block_sum(l1, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_out + 0, seg * inv_count);
+        atomicAdd(loss_out + 1, l1 * inv_count / 256.f);
+    }
+}
+
 // argmax over the last dimension of given probabilities (pix2pix_model.py:286): int32, ties -> lowest index
 __global__ void argmax_lastdim_kernel(const float* __restrict__ p, long long M, int C, int* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -137,6 +223,16 @@ extern "C" int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, con
     long long M = (long long)N * H * W;
     long long blocks = (M + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    const int vn = dtype == P2P_BF16 ? 8 : 4;
+    if (C == 256 && M < (1LL << 31) && z->ld % vn == 0 && ((uintptr_t)z->ptr % 16) == 0 &&
+        (!dz || !dz->ptr || (dz->ld % vn == 0 && ((uintptr_t)dz->ptr % 16) == 0)) && (!probs_out || ((uintptr_t)probs_out % 16) == 0)) {
+        long long b16 = (M + 15) / 16;               // 16 pixel groups per 256-thread workgroup
+        if (b16 > 8192) b16 = 8192;
+        P2P_DISPATCH_DTYPE(dtype, (softmax256_kernel<T><<<dim3((unsigned)b16), 256, 0, st>>>(
+                                      N, PixDec::make(H, W), make_view(z), make_view(target), make_view(fake_idx), grad_scale, inv_count,
+                                      d, probs_out, loss_out)));
+        return p2p_check_launch("p2p_softmax_cce_argmax");
+    }
     if (C == 256)
         P2P_REQUIRE(z->ld % 4 == 0 && ((uintptr_t)z->ptr % 16) == 0 && (!dz || !dz->ptr || (dz->ld % 4 == 0 && ((uintptr_t)dz->ptr % 16) == 0)),
                     "p2p_softmax_cce_argmax: 256-way views must be 4-channel aligned");
