@@ -20,6 +20,8 @@ struct WsArgs {
     int N, LH, LW, Cg, Cd;
     int TH;                        // lo rows per strip
     int strips_per_img, nstrips;   // LH / TH, N * strips_per_img
+    int pack;                      // 0: one tap per MFMA tile row block.  Few-channel sides (8-channel = 16-byte pixels, bf16):
+                                   // 1: a hi tile holds 4 taps x 8 hi channels, 2: a lo tile holds 4 taps x 8 lo channels
 };
 
 __device__ __forceinline__ void glds16s(const char* g, char* l) {
@@ -73,13 +75,14 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                 glds16s(src, hiL + cI * 16);       // wave-uniform base + lane*16
             }
         }
-        const int lchunks_row = lrowB >> 4, lchunks = TH * lchunks_row, lcpp = lpB >> 4;
+        const int LWp = a.pack == 2 ? TW + 3 : TW, LHp = a.pack == 2 ? TH + 3 : TH, lo_org = a.pack == 2 ? -2 : 0;
+        const int lchunks_row = (LWp * lpB) >> 4, lchunks = LHp * lchunks_row, lcpp = lpB >> 4;
         for (int cI = wave * 64; cI < lchunks; cI += NTHR) {
             int ci = cI + lane;
             if (ci < lchunks) {
                 int rr = ci / lchunks_row, cc = ci - rr * lchunks_row;
                 int px = cc / lcpp, ch = cc - px * lcpp;
-                const char* src = a.lo + ((long long)n * a.lo_img + (long long)(y0 + rr) * a.lo_row + px) * lgB +
+                const char* src = a.lo + ((long long)n * a.lo_img + (long long)(y0 + lo_org + rr) * a.lo_row + lo_org + px) * lgB +
                                   (lpB == lgB ? 0 : d0 * ESZ) + ch * 16;
                 glds16s(src, loL + cI * 16);
             }
@@ -90,6 +93,39 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
         if constexpr (ESZ == 2) {
             const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
             const int chB = (16 * (grp & 1) + 4 * p) * 2;            // byte offset of this lane's 4 channels inside a 32-channel tile
+            if (a.pack) {
+                // Packed taps (8 waves): the 32 channel slots of the few-channel operand's tile are 4 taps (kw = 0..3 of
+                // kernel row kh = wave & 3) x 8 channels -- a lane's 4-channel chunk belongs to tap kw = 2 (grp & 1) + (p >> 1),
+                // channels 4 (p & 1) .., and supplies that tap's pixel address to the transposing read.  The other operand
+                // is read once per 16-pixel K step for all four taps; wave >> 2 picks its 32-channel tile.
+                const int kh = wave & 3, tsel = wave >> 2;
+                const int kw = 2 * (grp & 1) + (p >> 1);
+                const int chP = 4 * (p & 1) * 2;
+                for (int yy = 0; yy < TH; ++yy) {
+                    for (int x0 = 0; x0 < TW; x0 += 16) {
+                        s16x4 rh[2], rl[2];
+#pragma unroll
+                        for (int rd = 0; rd < 2; ++rd) {
+                            const int x = x0 + 8 * (grp >> 1) + 4 * rd + q;
+                            int offh, offl;
+                            if (a.pack == 1) {       // K runs over lo pixels (yy, x); hi carries the taps
+                                offh = ((S * yy + kh) * RW + S * x + kw) * hpB + chP;
+                                offl = (yy * TW + x) * lpB + tsel * 64 + chB;
+                            } else {                 // stride 1, K runs over hi INTERIOR pixels (yy, x); lo (haloed strip) carries the taps
+                                offh = ((yy + 1) * RW + x + 1) * hpB + tsel * 64 + chB;
+                                offl = ((yy - kh + 3) * (TW + 3) + (x - kw + 3)) * lpB + chP;
+                            }
+                            rh[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiL + offh));
+                            rl[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loL + offl));
+                        }
+                        union { s16x4 h[2]; bf16x8 v; } uh, ul;
+                        uh.h[0] = rh[0]; uh.h[1] = rh[1];
+                        ul.h[0] = rl[0]; ul.h[1] = rl[1];
+                        acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh.v, ul.v, acc[0][0][0], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
             for (int yy = 0; yy < TH; ++yy) {
                 for (int x0 = 0; x0 < TW; x0 += 16) {
                     bf16x8 bfr[DT];
@@ -154,6 +190,21 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
     float* outp = a.part + (long long)blockIdx.x * 16 * a.Cg * a.Cd;
     const int gwin = (hpB == hgB) ? 0 : g0, dwin = (lpB == lgB) ? 0 : d0;      // whole-pixel staging covers window 0 only
     const int h = lane >> 5;
+    if (a.pack) {
+        // D[row][col]: the packed side's index is (kw = idx >> 3, channel = idx & 7) of kernel row kh = wave & 3
+        if (wave < 8) {
+            const int kh = wave & 3, tsel = wave >> 2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h, col = lane & 31;
+                int tap, g, d;
+                if (a.pack == 1) { tap = kh * 4 + (row >> 3); g = row & 7; d = dwin + tsel * 32 + col; }
+                else { tap = kh * 4 + (col >> 3); g = gwin + tsel * 32 + row; d = col & 7; }
+                if (g < a.Cg && d < a.Cd) outp[((long long)tap * a.Cg + g) * a.Cd + d] = acc[0][0][0][e];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tap = wave * TPW + t;
@@ -204,6 +255,11 @@ static int ws_sum_split(int nslabs, int n) {
 // 16 waves (one tap each) instead of 8 (two taps each): 8 % slower alone, but +1.8 % on the whole step (three A/B
 // repeats on one device, r01) -- this kernel runs on the side stream next to the data-gradient chain, where the extra
 // waves keep it issuing while the other stream's workgroups hold most of the CU
+static int ws_pack_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("P2P_WS_PACK"); v = e ? atoi(e) : 1; }
+    return v;
+}
 static int ws_waves16() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("P2P_WS_W16"); v = e ? atoi(e) : 1; }
@@ -211,10 +267,10 @@ static int ws_waves16() {
 }
 
 // Tiling of the LDS-resident form: 32x32 MFMA tiles per workgroup (GT x DT <= 4), channel windows, strip height.
-struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks; size_t shm; };
+struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks, pack; size_t shm; };
 
 static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
-    WsPlan p = {0, 0, 0, 0, 0, 0, 0, 0};
+    WsPlan p = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int esz = dtype == P2P_BF16 ? 2 : 4;
     if ((LW & (LW - 1)) || LW < 16 || LW > 64) return p;
     if ((hi_ld * esz) % 16 || (lo_ld * esz) % 16) return p;
@@ -226,6 +282,11 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     p.gwins = (gt_all + p.GT - 1) / p.GT;
     p.dwins = (dt_all + p.DT - 1) / p.DT;
     if (p.gwins * p.dwins > 8) return p;                 // beyond that the general kernel (wgemm.hip) re-reads less
+    // few-channel sides stored as one 16-byte pixel (bf16): pack 4 taps x 8 channels into one 32-slot tile
+    if (ws_pack_on() && dtype == P2P_BF16 && p.gwins == 1 && p.dwins == 1) {
+        if (hi_ld == 8 && Cg <= 8 && p.GT == 1 && p.DT == 2) p.pack = 1;                       // 4/8 -> 64 (down1, D.down)
+        else if (stride == 1 && lo_ld == 8 && Cd <= 8 && p.GT == 2 && p.DT == 1) p.pack = 2;   // 36 -> 4, 64 -> 1 (the heads)
+    }
     int TH = 512 / LW;
     if (TH > 8) TH = 8;
     if (TH > LH) TH = LH;
@@ -234,7 +295,7 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
         const size_t hpB = (size_t)hi_ld * esz > (size_t)64 * p.GT * (esz / 2) ? (size_t)64 * p.GT * (esz / 2) : (size_t)hi_ld * esz;
         const size_t lpB = (size_t)lo_ld * esz > (size_t)64 * p.DT * (esz / 2) ? (size_t)64 * p.DT * (esz / 2) : (size_t)lo_ld * esz;
         const size_t hi_bytes = (size_t)(stride * TH + 3) * (stride * LW + 3) * hpB;
-        const size_t lo_bytes = (size_t)TH * LW * lpB;
+        const size_t lo_bytes = p.pack == 2 ? (size_t)(TH + 3) * (LW + 3) * lpB : (size_t)TH * LW * lpB;
         p.shm = ((hi_bytes + 15) & ~(size_t)15) + 256 + lo_bytes + 512;
         if (p.shm <= 150 * 1024) break;
         if (TH == 1) return p;
@@ -270,7 +331,7 @@ static int ws_launch(WsArgs& a, int stride, const WsPlan& p, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)wgrad_small_kernel<T, S_, G_, D_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             done = true;                                                                                               \
         }                                                                                                              \
-        if (ws_waves16()) wgrad_small_kernel<T, S_, G_, D_, 1><<<grid, dim3(1024), p.shm, st>>>(a);                    \
+        if (ws_waves16() && !p.pack) wgrad_small_kernel<T, S_, G_, D_, 1><<<grid, dim3(1024), p.shm, st>>>(a);         \
         else wgrad_small_kernel<T, S_, G_, D_, 2><<<grid, dim3(512), p.shm, st>>>(a);                                  \
     } while (0)
 #define WS_SEL(S_)                                                                                                     \
@@ -303,6 +364,7 @@ extern "C" int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int
     a.N = N; a.LH = LH; a.LW = LW; a.Cg = Cg; a.Cd = Cd;
     (void)esz;
     a.TH = plan.TH;
+    a.pack = plan.pack;
     a.strips_per_img = LH / plan.TH;
     a.nstrips = N * a.strips_per_img;
     hipStream_t st = (hipStream_t)stream;
