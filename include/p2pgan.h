@@ -293,6 +293,12 @@ int p2p_pack_input(int dtype, int N, int H, int W, int C, const void* src, int s
 /* same batch into ndst (1..4) views with one read (dsts = array of p2p_tensor). */
 int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
                          const p2p_tensor* dsts, int ndst, void* stream);
+/* The RGBA (4-channel) batch of a train step in one launch: source and target read once, whole-pixel stores into
+ * down1's input [source|0], channels 32..39 of the last concat buffer [source|0], the real half of the discriminator
+ * input [target|source] and the source half of its fake half.  Every view starts on an 8-channel boundary. */
+int p2p_pack_pair(int dtype, int N, int H, int W, const float* source, const float* target,
+                  const p2p_tensor* v_src, const p2p_tensor* v_c6, const p2p_tensor* v_dreal, const p2p_tensor* v_dfake,
+                  void* stream);
 /* out[7] = [g_total, g_adv, g_l1, g_aux, d_total, d_real, d_fake] from the loss slots written by the loss kernels:
  * slots[0..2] = BCE(1,real), BCE(0,fake), BCE(1,fake); slots[l1_slot] = L1; slots[aux_slot] = histogram /
  * segmentation loss (aux_slot < 0: none); g_total = adv + lambda_l1*l1 + lambda_aux*aux. */

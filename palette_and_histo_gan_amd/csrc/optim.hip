@@ -219,6 +219,55 @@ __global__ void pack_multi_kernel(int N, PixDec dec, int C, const void* __restri
     }
 }
 
+// The RGBA batch of a train step in ONE launch (dataset_utils.py:209-229 -> networks.py:45,92-94): per pixel one 16-byte read
+// of the source and of the target, and whole 16-byte pixel stores wherever the destination pixel is complete:
+//   v_src   [source | 0 0 0 0]            down1's input
+//   v_c6    [source | 0 0 0 0]            channels 32..39 of the last concat buffer
+//   v_dreal [target | source]             discriminator input, real half
+//   v_dfake [  ...  | source]             discriminator input, fake half: only the source half (the generator writes the rest)
+template <typename T>
+__global__ void pack_pair_kernel(int N, PixDec dec, const float* __restrict__ source, const float* __restrict__ target, TView v_src,
+                                 TView v_c6, TView v_dreal, TView v_dfake) {
+    typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+    typedef __attribute__((__vector_size__(8 * sizeof(T)))) T vec8_t;
+    const unsigned npix = (unsigned)N * dec.H * dec.W;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(p, n, y, x);
+        const f32x4 s4 = *(const f32x4*)(source + (long long)p * 4), t4 = *(const f32x4*)(target + (long long)p * 4);
+        vec4_t sq;
+        vec8_t sz, ts;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sq[k] = from_f32<T>(s4[k]);
+            sz[k] = sq[k]; sz[4 + k] = from_f32<T>(0.f);
+            ts[k] = from_f32<T>(t4[k]); ts[4 + k] = sq[k];
+        }
+        *(vec8_t*)((T*)v_src.ptr + v_src.off(n, y, x)) = sz;
+        *(vec8_t*)((T*)v_c6.ptr + v_c6.off(n, y, x)) = sz;
+        *(vec8_t*)((T*)v_dreal.ptr + v_dreal.off(n, y, x)) = ts;
+        *(vec4_t*)((T*)v_dfake.ptr + v_dfake.off(n, y, x) + 4) = sq;
+    }
+}
+
+extern "C" int p2p_pack_pair(int dtype, int N, int H, int W, const float* source, const float* target, const p2p_tensor* v_src,
+                             const p2p_tensor* v_c6, const p2p_tensor* v_dreal, const p2p_tensor* v_dfake, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && source && target && v_src && v_c6 && v_dreal && v_dfake, "p2p_pack_pair: bad args");
+    P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_pack_pair: too many pixels");
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    const p2p_tensor* vs[4] = {v_src, v_c6, v_dreal, v_dfake};
+    for (int k = 0; k < 4; ++k)
+        P2P_REQUIRE(vs[k]->ptr && vs[k]->ld % 8 == 0 && ((uintptr_t)vs[k]->ptr % (8 * esz)) == 0,
+                    "p2p_pack_pair: views must start on an 8-channel boundary (whole 16/32-byte pixels)");
+    P2P_REQUIRE(((uintptr_t)source % 16) == 0 && ((uintptr_t)target % 16) == 0, "p2p_pack_pair: batches must be 16-byte aligned");
+    long long blocks = ((long long)N * H * W + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    P2P_DISPATCH_DTYPE(dtype, (pack_pair_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
+                                  N, PixDec::make(H, W), source, target, make_view(v_src), make_view(v_c6), make_view(v_dreal),
+                                  make_view(v_dfake))));
+    return p2p_check_launch("p2p_pack_pair");
+}
+
 extern "C" int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
                                     const p2p_tensor* dsts, int ndst, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && src && dsts && ndst >= 1 && ndst <= 4, "p2p_pack_input_multi: bad args");

@@ -772,8 +772,14 @@ class Pix2PixEngine:
         Bg = global_batch or B
         self._dp = dp
         src_t, real_t = self._to_device(source, ic, B), self._to_device(real, ic, B)
-        self._pack_source(P, src_t, with_disc=True)
-        self._pack(P, real_t, P["dcat"].view(coff=0), ic)
+        if ic == 4 and self.src_ch == 8 and self.dcat_ch == 8:
+            # source and target in one launch, whole 16-byte pixels (networks.py:45,92-94)
+            L.call("p2p_pack_pair", self.dtype, B, S, S, _p(src_t), _p(real_t), C.byref(P["src"].view()),
+                   C.byref(P["c"][6].view(coff=UP_FILTERS[5])), C.byref(P["dcat"].view(coff=0)),
+                   C.byref(P["dcat"].view(coff=0, n0=B)), _stream())
+        else:
+            self._pack_source(P, src_t, with_disc=True)
+            self._pack(P, real_t, P["dcat"].view(coff=0), ic)
         if lambda_hist is not None:
             self._hist_real_early(P, B)
         self._early_side(P, masks, apply_update)
