@@ -261,6 +261,7 @@ class Pix2PixEngine:
         self.loss_part = torch.zeros(5 * 256, dtype=torch.float32, device=self.device)
         self.step_count = 0
         self._ticked = False
+        self._adam_head_ev = None
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
@@ -572,6 +573,12 @@ class Pix2PixEngine:
         with self.side.run():
             self._wgrad_impl(P, sid, name, N, lh, hi, lo, stride, dbias)
             dp = self._dp
+            if dp is None and sid == "G" and self.side.enabled and len(self.G.buckets) >= 2 \
+                    and self.G.bucket_last_layer[len(self.G.buckets) - 2] == name:
+                # every weight gradient in front of the last bucket has been issued: Adam may start on that part of the
+                # flat buffer while this stream is still busy with the last layers (see _finish_step)
+                self._adam_head_ev = torch.cuda.Event()
+                self._adam_head_ev.record(torch.cuda.current_stream())
             if dp is not None and sid == "G":
                 b = self.G.bucket_of[name]
                 if self.G.bucket_last_layer[b] == name and b != len(self.G.buckets) - 1:
@@ -873,26 +880,43 @@ class Pix2PixEngine:
         self._dp = None
 
     def _finish_step(self, P, lambda_l1, lambda_hist, apply_update):
+        head = self._adam_head(apply_update)
         self.side.join()
         L.call("p2p_loss_partials_sum", _p(self.loss_part), 4, _p(self.losses), _stream())
         self._reduce_tail()
         if apply_update:
-            self.apply_adam()
+            self.apply_adam(g_from=head)
         out = torch.empty(8, dtype=torch.float32, device=self.device)
         L.call("p2p_finish_losses", _p(self.losses), 4 if lambda_hist is not None else -1, 3, float(lambda_l1),
                float(lambda_hist) if lambda_hist is not None else 0.0, _p(out), _stream())
         self.step_count += 1
         return out[:7]
 
-    def apply_adam(self):
-        """Both optimizers step with gradients taken at the same pre-update weights (pix2pix_model.py:81-83)."""
+    def _adam_head(self, apply_update):
+        """Single-GPU steps: the main stream finishes the backward pass ~70 us before the weight-gradient stream does (the
+        last layers' weight gradients are issued last).  Adam on the part of the generator's flat buffer whose gradients
+        are already complete -- everything in front of the last bucket, 90 % of the parameters -- runs in that window: a
+        memory-bound kernel next to the compute-bound tail of the other stream.  Returns the first element still to update."""
+        ev, self._adam_head_ev = self._adam_head_ev, None
+        if ev is None or not apply_update or not self._ticked or self._dp is not None:
+            return 0
+        torch.cuda.current_stream().wait_event(ev)      # also orders the Adam step counters (ticked on that stream) before us
+        n = self.G.buckets[-1][0]
+        L.call("p2p_adam_flat_dev", _p(self.G.params), _p(self.G.grads), _p(self.G.m), _p(self.G.v), n,
+               _p(self.G.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+        return n
+
+    def apply_adam(self, g_from=0):
+        """Both optimizers step with gradients taken at the same pre-update weights (pix2pix_model.py:81-83).  `g_from`:
+        first generator element not yet updated by _adam_head."""
         ticked, self._ticked = self._ticked, False      # counters already advanced by _early_side of this step
         for store in (self.G, self.D):
             store.t += 1
             if not ticked:
                 L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
-            L.call("p2p_adam_flat_dev", _p(store.params), _p(store.grads), _p(store.m), _p(store.v), store.numel,
-                   _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+            off = g_from if store is self.G else 0
+            L.call("p2p_adam_flat_dev", _p(store.params, off), _p(store.grads, off), _p(store.m, off), _p(store.v, off),
+                   store.numel - off, _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
         if not ticked:
             L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
         self.refresh_weight_copies()
@@ -986,11 +1010,12 @@ class Pix2PixEngine:
         P["skip_g_through_d"] = True
         self.discriminator_backward(P, B)
         self.generator_backward(P)
+        head = self._adam_head(apply_update)
         self.side.join()
         L.call("p2p_loss_partials_sum", _p(self.loss_part), 3, _p(self.losses), _stream())
         self._reduce_tail()
         if apply_update:
-            self.apply_adam()
+            self.apply_adam(g_from=head)
         out = torch.empty(8, dtype=torch.float32, device=self.device)
         # g_total = adv + 0 * l1 + lambda_seg * seg  (lambda_l1 is hard-wired to 0, pix2pix_model.py:263,273-278)
         L.call("p2p_finish_losses", _p(self.losses), 5, 6, 0.0, float(lambda_segmentation), _p(out), _stream())
