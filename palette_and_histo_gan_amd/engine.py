@@ -898,9 +898,16 @@ class Pix2PixEngine:
         are already complete -- everything in front of the last bucket, 90 % of the parameters -- runs in that window: a
         memory-bound kernel next to the compute-bound tail of the other stream.  Returns the first element still to update."""
         ev, self._adam_head_ev = self._adam_head_ev, None
-        if ev is None or not apply_update or not self._ticked or self._dp is not None:
+        if not apply_update or not self._ticked or len(self.G.buckets) < 2:
             return 0
-        torch.cuda.current_stream().wait_event(ev)      # also orders the Adam step counters (ticked on that stream) before us
+        if self._dp is not None:
+            # data parallel: the buckets in front of the last one were all-reduced asynchronously during the backward pass;
+            # once those collectives are done their sums are final (the last bucket and the tail follow in _reduce_tail)
+            self._dp.wait_all()
+        elif ev is not None:
+            torch.cuda.current_stream().wait_event(ev)      # also orders the Adam step counters (ticked on that stream) before us
+        else:
+            return 0
         n = self.G.buckets[-1][0]
         L.call("p2p_adam_flat_dev", _p(self.G.params), _p(self.G.grads), _p(self.G.m), _p(self.G.v), n,
                _p(self.G.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
