@@ -14,7 +14,8 @@ from collections import defaultdict
 
 FAMILIES = ["igemm_kernel", "wgemm_kernel", "wgrad_small_kernel", "conv_strip_kernel", "conv_fewin_kernel", "conv_fewout_kernel",
             "norm_act_fwd_vec", "norm_act_bwd_vec", "norm_act_fwd_small", "norm_act_bwd_small", "adam_flat_dev_kernel",
-            "weight_prep_batched_kernel", "act_bwd_vec_kernel", "pack_multi_kernel", "ws_slab_sum_kernel"]
+            "weight_prep_batched_kernel", "act_bwd_vec_kernel", "pack_pair_kernel", "ws_slab_sum_kernel", "rgbuv_hist_fwd_kernel",
+            "rgbuv_hist_bwd_kernel", "softmax256_kernel"]
 
 
 def main():
