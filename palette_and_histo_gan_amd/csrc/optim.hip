@@ -124,9 +124,48 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Cg, int Cd, 
 
 // Batched form: one launch re-derives the copies of every layer after an optimizer step.  Workgroup b serves the
 // task whose [first_block, first_block + 16 * tiles_g * tiles_d) range holds b (<= 64 tasks, scanned linearly).
+// 64x64 tiles with 16-byte reads and 4-element stores for the unpadded layers whose channel counts are multiples of 64
+// (every encoder/decoder block but up6): a quarter of the workgroups, whole 128/256-byte rows per wave access.
+static __host__ __device__ inline bool prep_tile64(int Cg, int Cd, int wn_rows, int wn_cols, int wt_rows, int wt_cols,
+                                                   bool have_wn, bool have_wt) {
+    return Cg % 64 == 0 && Cd % 64 == 0 && (!have_wn || (wn_rows == Cg && wn_cols == Cd)) &&
+           (!have_wt || (wt_rows == Cd && wt_cols == Cg));
+}
+
+template <typename T>
+__device__ __forceinline__ void weight_prep_tile64(const float* __restrict__ w, int Cg, int Cd, T* __restrict__ wn,
+                                                   T* __restrict__ wt, int t, int g0, int d0, float (*tile)[65]) {
+    typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+    const float* wp = w + (long long)t * Cg * Cd;
+    const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;         // 16 column quads x 16 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i;
+        const f32x4 v = *(const f32x4*)(wp + (long long)(g0 + r) * Cd + d0 + c4);
+        tile[r][c4] = v[0]; tile[r][c4 + 1] = v[1]; tile[r][c4 + 2] = v[2]; tile[r][c4 + 3] = v[3];
+        if (wn) {
+            vec4_t q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = from_f32<T>(v[k]);
+            *(vec4_t*)(wn + ((long long)t * Cg + g0 + r) * Cd + d0 + c4) = q;
+        }
+    }
+    __syncthreads();
+    if (wt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = r0 + 16 * i;
+            vec4_t q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = from_f32<T>(tile[c4 + k][d]);
+            *(vec4_t*)(wt + ((long long)t * Cd + d0 + d) * Cg + g0 + c4) = q;
+        }
+    }
+}
+
 template <typename T>
 __global__ void weight_prep_batched_kernel(const p2p_prep_task* __restrict__ tasks, int ntasks) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     const long long b = blockIdx.x;
     int ti = 0;
     while (ti + 1 < ntasks && tasks[ti + 1].first_block <= b) ++ti;
@@ -135,7 +174,12 @@ __global__ void weight_prep_batched_kernel(const p2p_prep_task* __restrict__ tas
     const int per_tap = k.tiles_g * k.tiles_d;
     const int t = local / per_tap, rem = local - t * per_tap;
     const int gy = rem / k.tiles_d, dx = rem - gy * k.tiles_d;
-    weight_prep_tile<T>(k.w, k.Cg, k.Cd, (T*)k.wn, k.wn_rows, k.wn_cols, (T*)k.wt, k.wt_rows, k.wt_cols, t, gy * 32, dx * 32, tile);
+    if (prep_tile64(k.Cg, k.Cd, k.wn_rows, k.wn_cols, k.wt_rows, k.wt_cols, k.wn != nullptr, k.wt != nullptr)) {
+        weight_prep_tile64<T>(k.w, k.Cg, k.Cd, (T*)k.wn, (T*)k.wt, t, gy * 64, dx * 64, tile);
+        return;
+    }
+    weight_prep_tile<T>(k.w, k.Cg, k.Cd, (T*)k.wn, k.wn_rows, k.wn_cols, (T*)k.wt, k.wt_rows, k.wt_cols, t, gy * 32, dx * 32,
+                        (float (*)[33])tile);
 }
 
 extern "C" long long p2p_weight_prep_task_blocks(int Cg, int Cd, int wn_rows, int wn_cols, int wt_rows, int wt_cols,
@@ -143,7 +187,8 @@ extern "C" long long p2p_weight_prep_task_blocks(int Cg, int Cd, int wn_rows, in
     int gmax = Cg, dmax = Cd;
     if (have_wn) { gmax = gmax > wn_rows ? gmax : wn_rows; dmax = dmax > wn_cols ? dmax : wn_cols; }
     if (have_wt) { gmax = gmax > wt_cols ? gmax : wt_cols; dmax = dmax > wt_rows ? dmax : wt_rows; }
-    const int tg = (gmax + 31) / 32, td = (dmax + 31) / 32;
+    const int ts = prep_tile64(Cg, Cd, wn_rows, wn_cols, wt_rows, wt_cols, have_wn != 0, have_wt != 0) ? 64 : 32;
+    const int tg = (gmax + ts - 1) / ts, td = (dmax + ts - 1) / ts;
     if (tiles_g) *tiles_g = tg;
     if (tiles_d) *tiles_d = td;
     return 16LL * tg * td;

@@ -308,6 +308,36 @@ def test_bad_arguments_fail_loudly():
         L.call("p2p_conv_direct", 7, 2, L.F32, 1, 4, 4, 4, 4, C.byref(t), C.byref(t), None, None, None, None, None)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weight_prep_batched_equals_per_layer(dtype):
+    """One batched launch (64x64 vector tiles where the shape allows, 32x32 tiles and padding elsewhere) == the per-layer
+    kernel, bit for bit."""
+    rng = np.random.default_rng(23)
+    specs = [(64, 128, 64, 128, 128, 64), (128, 64, 128, 64, 64, 128), (32, 128, 32, 128, 128, 32),
+             (36, 4, 64, 8, 32, 40), (4, 64, 32, 64, 64, 8), (512, 512, 512, 512, 512, 512)]
+    tasks = (L.PrepTask * len(specs))()
+    keep, first = [], 0
+    for k, (cg, cd, wn_r, wn_c, wt_r, wt_c) in enumerate(specs):
+        w = U.dev(rng.normal(size=16 * cg * cd).astype(np.float32))
+        wn = torch.full((16 * wn_r * wn_c,), float("nan"), dtype=U.tdt(dtype), device=U.DEV)
+        wt = torch.full((16 * wt_r * wt_c,), float("nan"), dtype=U.tdt(dtype), device=U.DEV)
+        wn_ref, wt_ref = torch.empty_like(wn), torch.empty_like(wt)
+        L.call("p2p_weight_prep_pad", dtype, U.ptr(w), cg, cd, U.ptr(wn_ref), wn_r, wn_c, U.ptr(wt_ref), wt_r, wt_c, U.stream())
+        tg, td = C.c_int(0), C.c_int(0)
+        nb = L.lib().p2p_weight_prep_task_blocks(cg, cd, wn_r, wn_c, wt_r, wt_c, 1, 1, C.byref(tg), C.byref(td))
+        t = tasks[k]
+        t.w, t.wn, t.wt = w.data_ptr(), wn.data_ptr(), wt.data_ptr()
+        t.Cg, t.Cd, t.wn_rows, t.wn_cols, t.wt_rows, t.wt_cols = cg, cd, wn_r, wn_c, wt_r, wt_c
+        t.tiles_g, t.tiles_d, t.first_block = tg.value, td.value, first
+        first += nb
+        keep.append((w, wn, wt, wn_ref, wt_ref))
+    table = torch.frombuffer(bytearray(bytes(tasks)), dtype=torch.uint8).to(U.DEV)
+    L.call("p2p_weight_prep_batched", dtype, U.ptr(table), len(specs), first, U.stream())
+    for w, wn, wt, wn_ref, wt_ref in keep:
+        assert torch.equal(wn.view(torch.int16 if dtype == L.BF16 else torch.int32), wn_ref.view(torch.int16 if dtype == L.BF16 else torch.int32))
+        assert torch.equal(wt.view(torch.int16 if dtype == L.BF16 else torch.int32), wt_ref.view(torch.int16 if dtype == L.BF16 else torch.int32))
+
+
 def _pad_view_input(x, cpad, dtype):
     """numpy (N,H,W,C) -> HaloBuf with C padded (zeros) to cpad channels."""
     n, h, w, c = x.shape
