@@ -21,7 +21,7 @@ struct FiArgs {
     int LH, LW, lgLW;
     int ncols;
     int mode, S;                                           // 0 = G (stride S), 2 = P stride 1
-    int TH, strips_per_img;
+    int TH, strips_per_img, nstrips;
     int RH, RW;                                            // input pixels the strip touches
     int vec;                                               // output view allows 16-byte stores
 };
@@ -34,7 +34,6 @@ __global__ __launch_bounds__(256 * NT) void conv_fewin_kernel(FiArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = wave >> 2, wv = wave & 3;
     const int h = lane >> 5, r = lane & 31;
-    const int n = blockIdx.x / a.strips_per_img, y0 = (blockIdx.x % a.strips_per_img) * a.TH;
     const int RW = a.RW, S = a.S;
     constexpr int PROW = 64 + 16;                           // patch row: 32 bf16 channels + 16 B pad
     constexpr int PATCH = 32 * PROW;                        // per-wave transpose patch
@@ -59,6 +58,10 @@ __global__ __launch_bounds__(256 * NT) void conv_fewin_kernel(FiArgs a) {
     }
     if (tid < NT * 32) bL[tid] = (a.bias && tid < a.ncols) ? a.bias[tid] : 0.f;
 
+    // persistent workgroups: the weights are fetched once, then the workgroup walks over its strips
+    for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x) {
+    const int n = strip / a.strips_per_img, y0 = (strip - n * a.strips_per_img) * a.TH;
+    __syncthreads();                     // every wave is done with the previous strip (and the bias is in LDS)
     // ---- stage the strip ----------------------------------------------------------------------------------------------------
     {
         const int oy = a.mode == 0 ? S * y0 - 1 : y0 - 2;
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(256 * NT) void conv_fewin_kernel(FiArgs a) {
         }
         __builtin_amdgcn_wave_barrier();       // the patch is rewritten by the next tile
     }
+    }
 }
 
 struct FiPlan { int ok, NT, TH, RH, RW; size_t shm; };
@@ -175,11 +179,11 @@ extern "C" int p2p_conv_fewin(int op, int stride, int dtype, int N, int LH, int 
     a.ncols = ncols;
     a.mode = op == P2P_OP_G ? 0 : 2;
     a.S = op == P2P_OP_G ? stride : 1;
-    a.TH = p.TH; a.strips_per_img = LH / p.TH;
+    a.TH = p.TH; a.strips_per_img = LH / p.TH; a.nstrips = N * a.strips_per_img;
     a.RH = p.RH; a.RW = p.RW;
     a.vec = out->ld % 8 == 0 && ((uintptr_t)out->ptr % 16) == 0;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(N * a.strips_per_img));
+    const dim3 grid((unsigned)(a.nstrips < 1024 ? a.nstrips : 1024));      // <= 4 persistent workgroups per CU
     if (p.NT == 1) conv_fewin_kernel<1><<<grid, dim3(256), p.shm, st>>>(a);
     else conv_fewin_kernel<2><<<grid, dim3(512), p.shm, st>>>(a);
     return p2p_check_launch("p2p_conv_fewin");
