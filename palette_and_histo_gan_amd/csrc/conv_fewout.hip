@@ -24,7 +24,7 @@ struct FoArgs {
     int C;                               // contraction channels (multiple of 8, <= 16 * KS)
     int ncols;
     int mode;                            // 0 = G stride 1, 1 = P stride 2
-    int TH, strips_per_img;
+    int TH, strips_per_img, nstrips;
     int RH, RW;                          // input pixels the strip touches
 };
 
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(512) void conv_fewout_kernel(FoArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r = lane & 31;
-    const int n = blockIdx.x / a.strips_per_img, y0 = (blockIdx.x % a.strips_per_img) * a.TH;
     const int C = a.C, RW = a.RW, TH = a.TH;
 
     // ---- weights: row (tap, o) of fragment f is lane r's A row ---------------------------------------------------------
@@ -98,6 +97,10 @@ __global__ __launch_bounds__(512) void conv_fewout_kernel(FoArgs a) {
         }
     }
 
+    // persistent workgroups (two per CU): the weights stay in registers, the workgroup walks over its strips
+    for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x) {
+    const int n = strip / a.strips_per_img, y0 = (strip - n * a.strips_per_img) * a.TH;
+    __syncthreads();                 // the previous strip's taps have been gathered: Z may be overwritten
     // ---- Z = W^T x for every input pixel of the strip; keep the (input row, kh) pairs some output row of the strip uses ---
     const int gpB = a.in_ld * ESZ;
     const char* in0 = a.in + ((long long)n * a.in_img + (long long)(y0 - 1) * a.in_row - 1) * gpB;
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(512) void conv_fewout_kernel(FoArgs a) {
                 if (o < a.ncols) op[o] = from_f32<T>(v[o]);
         }
     }
+    }
 }
 
 struct FoPlan { int ok, KS, OS, TH, RH, RW; size_t shm; };
@@ -244,10 +248,10 @@ extern "C" int p2p_conv_fewout(int op, int stride, int dtype, int N, int LH, int
     while ((1 << a.lgLW) < LW) ++a.lgLW;
     a.C = cin_pad; a.ncols = ncols;
     a.mode = op == P2P_OP_G ? 0 : 1;
-    a.TH = p.TH; a.strips_per_img = LH / p.TH;
+    a.TH = p.TH; a.strips_per_img = LH / p.TH; a.nstrips = N * a.strips_per_img;
     a.RH = p.RH; a.RW = p.RW;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(N * a.strips_per_img));
+    const dim3 grid((unsigned)(a.nstrips < 512 ? a.nstrips : 512));
 #define FO_GO(KS_, OS_)                                                                                                \
     do {                                                                                                               \
         static bool done = false;                                                                                      \
