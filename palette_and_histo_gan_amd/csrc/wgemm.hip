@@ -200,13 +200,14 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
         }
 }
 
+// out = sum of the msplit partial slabs, fixed order; four outputs per lane (n = 16 * Cg * Cd is a multiple of 16)
 __global__ void slab_sum_kernel(const float* __restrict__ part, int nslabs, long long n, float* __restrict__ out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
     for (; i < n; i += stride) {
-        float s = 0.f;
-        for (int k = 0; k < nslabs; ++k) s += part[(long long)k * n + i];
-        out[i] = s;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nslabs; ++k) s += *(const f32x4*)(part + (long long)k * n + i);
+        *(f32x4*)(out + i) = s;
     }
 }
 
@@ -275,7 +276,7 @@ static int wgemm_common(int dtype, int stride, int N, int LH, int LW, int Cg, in
     if (rc) return rc;
     if (msplit > 1) {
         long long n = 16LL * Cg * Cd;
-        long long blocks = (n + 255) / 256;
+        long long blocks = (n / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         slab_sum_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>((const float*)workspace, msplit, n, dw);
         return p2p_check_launch("p2p_wgemm reduce");
