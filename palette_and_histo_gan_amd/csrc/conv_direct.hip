@@ -177,6 +177,41 @@ __global__ __launch_bounds__(256) void view_colsum_vec(int N, int LH, int LW, in
     }
 }
 
+// Narrow form (8-channel pixels, Cd <= 8: the bias gradients of the two heads): one whole pixel per lane and step
+// (16 / 32 bytes), 8 running sums per lane, one LDS tree and one atomic per channel and workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void view_colsum_px8(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk) {
+    __shared__ float red[8][256];
+    const int M = N * LH * LW;
+    const int m0 = blockIdx.x * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int m = m0 + threadIdx.x; m < m1; m += 256) {
+        const int x = m % LW, q = m / LW, y = q % LH, n = q / LH;
+        const T* p = (const T*)lo.ptr + lo.off(n, y, x);
+        if (sizeof(T) == 2) {
+            const bf16x8 r = *(const bf16x8*)p;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += (float)r[k];
+        } else {
+            const f32x4 r0 = *(const f32x4*)p, r1 = *(const f32x4*)((const float*)p + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[k] += r0[k]; acc[4 + k] += r1[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x < Cd) atomicAdd(out + threadIdx.x, red[threadIdx.x][0]);
+}
+
 // out[d] = sum over all pixels of v[m][d]  (bias gradients of the two stride-1 heads, networks.py:47-48,75-78)
 extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && v && v->ptr && out, "p2p_view_colsum: bad args");
@@ -185,6 +220,11 @@ extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_
     if (e != hipSuccess) { p2p_set_error("p2p_view_colsum memset: %s", hipGetErrorString(e)); return (int)e; }
     long long M = (long long)N * H * W;
     P2P_REQUIRE(M < (1LL << 31), "p2p_view_colsum: too many pixels");
+    if (C <= 8 && v->ld == 8 && ((uintptr_t)v->ptr % 16) == 0) {
+        const int chunk8 = 4096;                 // 256 workgroups at 256 x 64 x 64
+        P2P_DISPATCH_DTYPE(dtype, (view_colsum_px8<T><<<dim3((unsigned)((M + chunk8 - 1) / chunk8)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunk8)));
+        return p2p_check_launch("p2p_view_colsum");
+    }
     const int vn = dtype == P2P_BF16 ? 8 : 4;
     if (C >= 64 && C % vn == 0 && C / vn <= 256 && 256 % (C / vn) == 0 && v->ld % vn == 0 && ((uintptr_t)v->ptr % 16) == 0) {
         const int chunkv = 1024;                 // pixels per workgroup: 512 workgroups at 128 x 64 x 64
