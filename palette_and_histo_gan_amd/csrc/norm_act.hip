@@ -3,6 +3,7 @@
 // Concatenate at networks.py:18-19,29-34,94; backward = the tape gradient of that chain, closed form in
 // SURVEY.md 8a A13 (checked against autograd in tests/test_oracle.py).
 #include "p2p_common.hpp"
+#include <stdlib.h>
 
 typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
 
@@ -870,11 +871,15 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
     if (vec) {
         int CG = C > 64 ? 64 : C;
         while (C % CG) CG -= vn;
+        // a pixel split was asked for, but 32-channel groups alone already give >= 1024 workgroups: take those and keep
+        // the one-launch form (no second read of x and the gradient from HBM)
+        const bool narrow = nsplit > 1 && CG == 64 && C % 32 == 0 && (long long)N * (C / 32) >= 1024 && H * W >= 64;
+        if (narrow) CG = 32;
         int vpp = CG / vn;
         if (256 % vpp == 0) {
             hipStream_t st = (hipStream_t)stream;
             const int prr = 256 / vpp;
-            int sp = nsplit < 1 ? 1 : nsplit;
+            int sp = (nsplit < 1 || narrow) ? 1 : nsplit;
             while (sp > 1 && (H * W + sp - 1) / sp < prr) sp >>= 1;
             if (!ws || (long long)N * sp * C * 2 * 4 > ws_bytes) sp = 1;
             dim3 grid(N, C / CG, sp);

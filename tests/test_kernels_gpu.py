@@ -167,7 +167,8 @@ def test_wgemm(dtype, n, lh, cg, cd, msplit):
     (2, 4, 64, L.ACT_LEAKY, False, True, 1), (3, 8, 32, L.ACT_RELU, True, True, 1), (2, 1, 512, L.ACT_LEAKY, False, True, 4),
     (2, 4, 36, L.ACT_RELU, True, True, 1), (2, 8, 64, L.ACT_LEAKY, False, False, 2), (2, 32, 32, L.ACT_RELU, False, True, 4),
     (3, 16, 128, L.ACT_LEAKY, True, True, 8),
-    (5, 2, 64, L.ACT_RELU, True, True, 1), (3, 3, 16, L.ACT_LEAKY, False, True, 1), (2, 2, 8, L.ACT_RELU, False, False, 1)])
+    (5, 2, 64, L.ACT_RELU, True, True, 1), (3, 3, 16, L.ACT_LEAKY, False, True, 1), (2, 2, 8, L.ACT_RELU, False, False, 1),
+    (256, 8, 128, L.ACT_LEAKY, True, True, 4)])      # >= 1024 (image, 32-channel) groups: the backward keeps one launch
 def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm, nsplit):
     rng = np.random.default_rng(13)
     nws = torch.empty(n * 16 * c * 2, dtype=torch.float32, device=U.DEV)
