@@ -87,6 +87,15 @@ int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd,
  * p2p_norm_act_fwd compute them).  p2p_norm_act_fwd consumes them with ws = stat_part, nsplit = -slots. */
 int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols);
 
+/* Block-resident form of p2p_igemm for the wide maps (bf16, LH == LW in {8,16,32,64}, splitk == 1; op P: Cd % 32 == 0 and
+ * Cg % 64 == 0, op G: Cg % 16 == 0 and Cd % 256 == 0): a workgroup keeps the input block of 256 lo pixels (with halo) in
+ * LDS, all taps / sub-pixel phases read it there and only the weights stream (csrc/brig.hip).  p2p_igemm takes this path
+ * by itself whenever p2p_brig_ok says the shape qualifies (environment P2P_BRIG=0 keeps the im2col kernel);
+ * p2p_igemm_layer_stat_slots is the statistics-slot query that matches the kernel p2p_igemm will use for the layer. */
+int p2p_brig_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+int p2p_brig_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+int p2p_igemm_layer_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+
 /* Edge-layer form of the same kernel (Cin 1..8, the 36/33-channel concat, Cout 1..4; networks.py:46-48,57,75-78):
  * stride 1 or 2, any contraction width that fills whole 16-byte chunks (`cin_pad` = channels of the gathered
  * view as padded in HBM and in `w`), output columns masked to `ncols` (launched in 32-wide tiles; `w_rows`, a

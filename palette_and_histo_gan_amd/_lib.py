@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libp2pgan_hip.so")
+LIB_PATH = os.environ.get("P2P_LIB") or os.path.join(HERE, "libp2pgan_hip.so")      # P2P_LIB: diagnostic builds (tools/ubench)
 
 F32, BF16 = 0, 1
 OP_G, OP_P, OP_W = 0, 1, 2
@@ -71,6 +71,9 @@ SIGNATURES = {
 }
 SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
            "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),
+           "p2p_brig_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
+           "p2p_brig_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
+           "p2p_igemm_layer_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_fewin_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_strip_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_strip_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),

@@ -21,6 +21,12 @@
 #include "p2p_common.hpp"
 #include <stdlib.h>
 
+// Diagnostic builds only (tools/ubench/igemm_abl.py): 1 = staging without the LDS reads / MFMAs, 2 = LDS reads + MFMAs
+// without the staging.  The product library is always built with 0.
+#ifndef P2P_ABL
+#define P2P_ABL 0
+#endif
+
 struct IgemmArgs {
     const char* in; long long in_img; int in_row; int in_ld;      // gathered input view (element strides)
     char* out; long long out_img; int out_row; int out_ld;        // output view, splitk == 1
@@ -199,8 +205,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
     // NST = 3: ring of three LDS stages, two K-blocks of loads in flight across the barrier: a counted s_waitcnt leaves
     //          the younger stage's LDS-DMA outstanding (cdna_hip_programming.md "Pipelining across barriers") -- for
     //          launches that put a single workgroup on each CU.
-    stage(0, smem);
-    if (NST == 3 && nkb > 1) stage(1, smem + STAGE);
+    if (P2P_ABL != 2) stage(0, smem);
+    if (P2P_ABL != 2 && NST == 3 && nkb > 1) stage(1, smem + STAGE);
     for (int kb = 0; kb < nkb; ++kb) {
         if (NST == 3) {
             if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
@@ -214,9 +220,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
         char* cur = smem + (NST == 3 ? (kb % 3) : (kb & 1)) * STAGE;
         const int kn = NST == 3 ? kb + 2 : kb + 1;                   // K-block to prefetch
         char* nxt = smem + (NST == 3 ? (kn % 3) : (kn & 1)) * STAGE;
-        if (kn < nkb) stage(kn, nxt);
+        if (P2P_ABL != 2 && kn < nkb) stage(kn, nxt);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; P2P_ABL != 1 && s < 4; ++s) {
             frag_t af[TM], bf[TN];
             const int q = 2 * s + h;
 #pragma unroll
@@ -521,12 +527,27 @@ extern "C" int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols) {
     return phases * (hw >= bm ? hw / bm : 1);
 }
 
+// block-resident form for the wide maps (brig.hip)
+extern "C" int p2p_brig_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+extern "C" int p2p_brig_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
+                const void* w, float* stat_part, void* stream);
+
+// Statistics slots of p2p_igemm for a layer, whichever of its two kernels takes the shape (block-resident form on the
+// wide bf16 maps, im2col form otherwise).
+extern "C" int p2p_igemm_layer_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd) {
+    if (p2p_brig_ok(op, dtype, N, LH, LW, Cg, Cd)) return p2p_brig_stat_slots(op, dtype, N, LH, LW, Cg, Cd);
+    return p2p_igemm_stat_slots(op, N, LH, LW, op == P2P_OP_G ? Cd : Cg);
+}
+
 extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
                          const p2p_tensor* lo, const void* w, int splitk, float* slabs, float* stat_part, void* stream) {
     P2P_REQUIRE(op == P2P_OP_G || op == P2P_OP_P, "p2p_igemm: op must be G or P");
     P2P_REQUIRE(N > 0 && LH > 0 && LW > 0, "p2p_igemm: bad shape");
     P2P_REQUIRE(Cg % 32 == 0 && Cd % 32 == 0 && Cg > 0 && Cd > 0, "p2p_igemm: Cg=%d, Cd=%d must be multiples of 32", Cg, Cd);
     P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && w, "p2p_igemm: null pointer");
+    if (splitk == 1 && p2p_brig_ok(op, dtype, N, LH, LW, Cg, Cd))
+        return brig_launch(op, dtype, N, LH, LW, Cg, Cd, hi, lo, w, stat_part, stream);
     const p2p_tensor* in = op == P2P_OP_G ? hi : lo;
     const p2p_tensor* out = op == P2P_OP_G ? lo : hi;
     const int C = op == P2P_OP_G ? Cg : Cd, ncols = op == P2P_OP_G ? Cd : Cg;

@@ -525,7 +525,7 @@ class Pix2PixEngine:
             sk = self._splitk(op, N, lh, cg, cd)
             slots = 0
             if want_stats and sk == 1:      # InstanceNorm statistics fused into the GEMM epilogue
-                slots = L.lib().p2p_igemm_stat_slots(op, N, lh, lh, cd if op == L.OP_G else cg)
+                slots = L.lib().p2p_igemm_layer_stat_slots(op, self.dtype, N, lh, lh, cg, cd)
                 if N * slots * (cd if op == L.OP_G else cg) * 2 > P["spart"].numel():
                     slots = 0
             slabs = P["slabs"]

@@ -454,7 +454,7 @@ def test_igemm_fused_instance_norm_statistics(dtype, op, n, lh, cg, cd):
     L.call("p2p_weight_prep", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
     ncols = cd if op == L.OP_G else cg
     res = lh if op == L.OP_G else 2 * lh
-    slots = L.lib().p2p_igemm_stat_slots(op, n, lh, lh, ncols)
+    slots = L.lib().p2p_igemm_layer_stat_slots(op, dtype, n, lh, lh, cg, cd)     # of whichever kernel p2p_igemm uses for the layer
     assert slots > 0
     assert L.lib().p2p_igemm_stat_slots(L.OP_P, n, 2, 2, ncols) == 0      # <= 16-pixel output maps take their own statistics
     out = E.DenseBuf(n, res, res, ncols, U.tdt(dtype), U.DEV)
@@ -479,6 +479,54 @@ def test_igemm_fused_instance_norm_statistics(dtype, op, n, lh, cg, cd):
     want = torch.relu(rg.instance_norm(torch.tensor(x), torch.tensor(gamma, dtype=F64), torch.tensor(beta, dtype=F64))).numpy()
     assert U.rel_err(U.halo_to_np(y), want) < OUT_TOL[dtype]
     np.testing.assert_allclose(stats[..., 0].cpu().numpy(), x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5 * np.abs(x).max())
+
+
+@pytest.mark.parametrize("op,n,lh,cg,cd", [
+    (L.OP_P, 3, 8, 64, 64), (L.OP_P, 5, 8, 128, 32), (L.OP_P, 9, 8, 64, 96), (L.OP_P, 2, 16, 64, 96), (L.OP_P, 1, 16, 128, 64),
+    (L.OP_P, 2, 32, 64, 32), (L.OP_P, 1, 64, 64, 32),
+    (L.OP_G, 3, 8, 32, 256), (L.OP_G, 5, 8, 64, 256), (L.OP_G, 2, 16, 64, 256), (L.OP_G, 1, 16, 96, 512), (L.OP_G, 2, 32, 32, 256),
+    (L.OP_G, 1, 64, 32, 256)])
+def test_igemm_block_resident_wide_maps(op, n, lh, cg, cd):
+    """bf16 wide maps: p2p_igemm runs the block-resident kernel (csrc/brig.hip: input block in LDS once, phases merged,
+    weights streamed); outputs and fused InstanceNorm statistics against the oracle, incl. ragged image groups (n = 3, 5, 9
+    on 8x8 maps: 4 images per workgroup), several K chunks and several output-channel tiles."""
+    dtype = L.BF16
+    assert L.lib().p2p_brig_ok(op, dtype, n, lh, lh, cg, cd) == 1
+    rng = np.random.default_rng(23)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, 2, dtype)
+    g_ref, p_ref, _ = oracle_ops(hi, lo, w, 2)
+    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
+    wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    w_d = U.dev(w.reshape(-1))
+    L.call("p2p_weight_prep", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
+    ref, shape = (g_ref, (n, lh, lh, cd)) if op == L.OP_G else (p_ref, (n, 2 * lh, 2 * lh, cg))
+    ncols, res = shape[3], shape[1]
+    slots = L.lib().p2p_igemm_layer_stat_slots(op, dtype, n, lh, lh, cg, cd)
+    assert slots == L.lib().p2p_brig_stat_slots(op, dtype, n, lh, lh, cg, cd) and slots >= 1
+    out = E.DenseBuf(*shape, U.tdt(dtype), U.DEV)
+    out.t.fill_(float("nan"))
+    spart = torch.full((n * slots * ncols * 2,), float("nan"), dtype=torch.float32, device=U.DEV)
+    hv, lv = (hi_b.view(), out.view()) if op == L.OP_G else (out.view(), lo_b.view())
+    L.call("p2p_igemm", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn), 1, None,
+           U.ptr(spart), U.stream())
+    got = U.dense_to_np(out)
+    assert np.isfinite(got).all()
+    assert U.rel_err(got, ref) < OUT_TOL[dtype]
+    x = got.astype(np.float64)
+    sp = spart.view(n, slots, ncols, 2).cpu().numpy().astype(np.float64)
+    cnt = res * res / slots
+    mean = sp[..., 0].mean(1)
+    m2 = sp[..., 1].sum(1) + cnt * ((sp[..., 0] - mean[:, None]) ** 2).sum(1)
+    np.testing.assert_allclose(mean, x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5 * np.abs(x).max())
+    np.testing.assert_allclose(m2 / (res * res), x.var(axis=(1, 2)), rtol=5e-4)
+    # without statistics, into a channel slice of a wider haloed buffer (concat-by-slice, networks.py:94)
+    wide = E.HaloBuf(n, res, res, ncols + 64, dtype, U.DEV)
+    hv, lv = (hi_b.view(), wide.view(coff=64)) if op == L.OP_G else (wide.view(coff=64), lo_b.view())
+    L.call("p2p_igemm", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn), 1, None,
+           None, U.stream())
+    back = U.halo_to_np(wide)
+    assert np.array_equal(back[..., 64:], got) and not back[..., :64].any()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
