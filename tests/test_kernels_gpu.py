@@ -481,15 +481,20 @@ def test_igemm_fused_instance_norm_statistics(dtype, op, n, lh, cg, cd):
     np.testing.assert_allclose(stats[..., 0].cpu().numpy(), x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5 * np.abs(x).max())
 
 
+@pytest.mark.parametrize("cbw", [1, 2])
 @pytest.mark.parametrize("op,n,lh,cg,cd", [
     (L.OP_P, 3, 8, 64, 64), (L.OP_P, 5, 8, 128, 32), (L.OP_P, 9, 8, 64, 96), (L.OP_P, 2, 16, 64, 96), (L.OP_P, 1, 16, 128, 64),
     (L.OP_P, 2, 32, 64, 32), (L.OP_P, 1, 64, 64, 32),
     (L.OP_G, 3, 8, 32, 256), (L.OP_G, 5, 8, 64, 256), (L.OP_G, 2, 16, 64, 256), (L.OP_G, 1, 16, 96, 512), (L.OP_G, 2, 32, 32, 256),
-    (L.OP_G, 1, 64, 32, 256)])
-def test_igemm_block_resident_wide_maps(op, n, lh, cg, cd):
-    """bf16 wide maps: p2p_igemm runs the block-resident kernel (csrc/brig.hip: input block in LDS once, phases merged,
-    weights streamed); outputs and fused InstanceNorm statistics against the oracle, incl. ragged image groups (n = 3, 5, 9
-    on 8x8 maps: 4 images per workgroup), several K chunks and several output-channel tiles."""
+    (L.OP_G, 1, 64, 32, 256), (L.OP_G, 2, 16, 64, 128)])
+def test_igemm_block_resident_wide_maps(op, n, lh, cg, cd, cbw, monkeypatch):
+    """bf16 wide maps: p2p_igemm runs the block-resident kernel (csrc/brig.hip: input block in LDS once, phases merged /
+    parity planes walked, weights streamed); outputs and fused InstanceNorm statistics against the oracle, incl. ragged
+    image groups (n = 3, 5, 9 on 8x8 maps: 4 images per workgroup), several K chunks and output-channel tiles, and both
+    wave tilings (64 or 32 output channels per wave)."""
+    if cbw == 2 and (cg if op == L.OP_P else cd) % (64 if op == L.OP_P else 256):
+        pytest.skip("the 64-channels-per-wave form needs whole 64 / 256 channel tiles")
+    monkeypatch.setenv("P2P_BRIG_CBW", str(cbw))
     dtype = L.BF16
     assert L.lib().p2p_brig_ok(op, dtype, n, lh, lh, cg, cd) == 1
     rng = np.random.default_rng(23)
