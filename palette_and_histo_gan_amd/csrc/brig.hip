@@ -47,6 +47,7 @@ struct BrigArgs {
     int abytes;              // bytes of one input block buffer
     int nkc;                 // K chunks (op P: C / 32; op G: 4 planes x C / 32)
     int rot;                 // lane rotation per block row on 16-wide maps (row pitch mod 16)
+    int stagger;             // waves 4-7 issue their DMA after their first MFMA group (P2P_BRIG_STAGGER, default on)
     long long in_lo;         // most negative byte offset from `in` that a block gathers: per-lane offsets are unsigned from there
 };
 
@@ -85,10 +86,11 @@ __device__ __forceinline__ void brig_lane_pixel(const BrigArgs& a, int pb, int i
 
 // pieces of the input block issued in step t of a K chunk (ahead of the step's weight stage)
 template <int NT> __host__ __device__ constexpr int brig_a_at(int t) { return NT == 4 ? (t < 2 ? 2 : 0) : (t < 1 ? 4 : 0); }
-// s_waitcnt count of step t: everything issued after this step's weight stage (NWST - 1 = 3 steps ahead) may stay in
+// s_waitcnt count of step t: everything issued after this step's weight stage (NWST - 1 steps ahead) may stay in
 // flight; at t = 0 the chunk's input block (issued in the previous chunk) must have landed too
-template <int NT> __host__ __device__ constexpr int brig_vm(int t) {
-    const int nw = (brig_a_at<NT>((t + NT - 1) % NT) + 2) + (brig_a_at<NT>((t + NT - 2) % NT) + 2);
+template <int NT, int NWST> __host__ __device__ constexpr int brig_vm(int t) {
+    int nw = 0;
+    for (int j = 1; j <= NWST - 2; ++j) nw += brig_a_at<NT>((t + 8 * NT - j) % NT) + 2;
     if (t != 0) return nw;
     int na = 2;                                      // the stage issued behind the block's last pieces ...
     const int last = NT == 4 ? 1 : 0;                // ... in step `last` of the previous chunk
@@ -98,12 +100,12 @@ template <int NT> __host__ __device__ constexpr int brig_vm(int t) {
 
 // MODE 1: op P (lo -> hi, four phases merged).   MODE 0: op G (hi -> lo, K chunks walk the four parity planes).
 // CBW: 32-channel blocks per wave (2: one tap per step; 1: two taps per step).
-template <int MODE, int CBW>
+template <int MODE, int CBW, int NWST>
 __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
     constexpr int CK = 32, RB = 64;         // channels per K chunk, bytes per LDS row (one pixel / one weight row of the chunk)
     constexpr int TPS = CBW == 2 ? 1 : 2;   // taps per step
     constexpr int NT = 4 / TPS;             // steps per K chunk
-    constexpr int NWST = 4, WST = 16384;    // weight ring
+    constexpr int WST = 16384;              // weight ring: NWST stages of 16 KB
     constexpr int PA = 4;                   // input-block pieces a wave issues per K chunk (duplicates pad the count)
     constexpr int CW = 32 * CBW;            // output channels per wave
     constexpr int PROW = CW * 2 + 16;       // epilogue patch row: CW channels bf16 + pad
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         if (step >= total) step = total - 1;
         const int kc = step / NT, t = step - kc * NT;
         const int tt0 = t * TPS;            // first tap of the step (TPS = 2: taps (a, 0) and (a, 1))
-        char* dst = Wring + (step & (NWST - 1)) * WST;
+        char* dst = Wring + (step % NWST) * WST;
         if (MODE == 1) {
             const long long coff = (long long)kc * CK * esz;
 #pragma unroll
@@ -231,26 +233,53 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
 #pragma unroll
     for (int s = 0; P2P_ABL != 2 && s < NWST - 1; ++s) issue_w(s);
 
+    // Software pipeline: a step has NS = 2 * TPS sub-steps (one 16-channel MFMA K step of one tap each).  Two fragment sets
+    // ping-pong, the loads of sub-step i+1 are issued before the MFMAs of sub-step i, and the MFMAs of a step's LAST sub-step
+    // are deferred to the start of the next step, behind its barrier and its first loads: the matrix pipe then has work while
+    // both waves of a SIMD wait for the barrier, the DMA issue and the first LDS reads (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+    constexpr int NS = 2 * TPS;
+    const bool stagger = a.stagger != 0;
+    bf16x8 wfA[CBW], afA[4], wfB[CBW], afB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) afB[i][e] = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wfB[i][e] = (bf16_t)0.f;
+    auto mfma_set = [&](const bf16x8 (&wf)[CBW], const bf16x8 (&af)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pbi = 0; pbi < 4; ++pbi)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+                acc[pbi][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb], af[pbi], acc[pbi][cb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
     for (int kc = 0; kc < a.nkc; ++kc) {
         const char* Acur = Abuf + (kc & 1) * a.abytes;
         // op P: the phase of this wave; op G: the parity plane of this chunk
         const int pq = MODE == 1 ? quarter : (kc & 3);
         brig_static_for(std::make_integer_sequence<int, NT>{}, [&](auto tt) {
             constexpr int t = decltype(tt)::value;
-            brig_wait_vm<brig_vm<NT>(t)>();
+            brig_wait_vm<brig_vm<NT, NWST>(t)>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // every wave has finished step s-1: its weight slot and (at t = 0) the other input buffer are free
-            if (P2P_ABL != 2) {
-                constexpr int na = brig_a_at<NT>(t);
-                constexpr int a0 = NT == 4 ? 2 * t : 0;
+            // every wave has finished reading step s-1: its weight slot and (at t = 0) the other input buffer are free
+            auto issue_dma = [&]() {
+                if (P2P_ABL != 2) {
+                    constexpr int na = brig_a_at<NT>(t);
+                    constexpr int a0 = NT == 4 ? 2 * t : 0;
 #pragma unroll
-                for (int i = 0; i < na; ++i) issue_a(kc + 1, a0 + i);
-                issue_w(kc * NT + t + NWST - 1);
-            }
-            const char* Wcur = Wring + ((kc * NT + t) & (NWST - 1)) * WST;
-#pragma unroll
-            for (int tp = 0; tp < TPS; ++tp) {
+                    for (int i = 0; i < na; ++i) issue_a(kc + 1, a0 + i);
+                    issue_w(kc * NT + t + NWST - 1);
+                }
+            };
+            const char* Wcur = Wring + ((kc * NT + t) % NWST) * WST;
+            auto load_set = [&](int sub, bf16x8 (&wf)[CBW], bf16x8 (&af)[4]) {
+                const int tp = sub >> 1, ks = sub & 1;
                 // tap (a, b) of the phase / plane reads block pixel (ly + da, lx + db): op P da = 1 + dy with dy = 0 / -1 (ph = 0),
                 // +1 / 0 (ph = 1); op G da = a
                 const int ta = (t * TPS + tp) >> 1, tb = (t * TPS + tp) & 1;
@@ -258,28 +287,36 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
                 if (MODE == 1) { da = 1 + (((pq >> 1) + 1 - ((1 - (pq >> 1)) + 2 * ta)) >> 1); db = 1 + (((pq & 1) + 1 - ((1 - (pq & 1)) + 2 * tb)) >> 1); }
                 else { da = ta; db = tb; }
                 const int toff = da * a.PITCH + db;
+                const int q = 2 * ks + h;
 #pragma unroll
-                for (int ks = 0; P2P_ABL != 1 && ks < 2; ++ks) {
-                    const int q = 2 * ks + h;
-                    bf16x8 wf[CBW], af[4];
+                for (int cb = 0; cb < CBW; ++cb) wf[cb] = *(const bf16x8*)(Wcur + woff[tp][ks][cb]);
 #pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb) wf[cb] = *(const bf16x8*)(Wcur + woff[tp][ks][cb]);
-#pragma unroll
-                    for (int pbi = 0; pbi < 4; ++pbi) {
-                        const int idx = aidx[pbi] + toff;
-                        af[pbi] = *(const bf16x8*)(Acur + idx * RB + ((q ^ ((idx >> 2) & 3)) << 4));
-                    }
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int pbi = 0; pbi < 4; ++pbi)
-#pragma unroll
-                        for (int cb = 0; cb < CBW; ++cb)
-                            acc[pbi][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb], af[pbi], acc[pbi][cb], 0, 0, 0);
-                    __builtin_amdgcn_s_setprio(0);
+                for (int pbi = 0; pbi < 4; ++pbi) {
+                    const int idx = aidx[pbi] + toff;
+                    af[pbi] = *(const bf16x8*)(Acur + idx * RB + ((q ^ ((idx >> 2) & 3)) << 4));
+                }
+            };
+            // The two waves of a SIMD (w and w + 4) would otherwise run the same program in lockstep behind the barrier: both
+            // issue their LDS-DMA (tens of cycles of issue time per instruction) while the matrix pipe idles.  The second half
+            // issues its DMA after its first MFMA group instead, so one partner multiplies while the other stages.
+            const bool late = stagger && half != 0;       // wave-uniform
+            if (!late || P2P_ABL == 1) issue_dma();
+            if (P2P_ABL != 1) {
+                load_set(0, wfA, afA);
+                mfma_set(wfB, afB);              // last sub-step of the previous step (zeros before the first one)
+                if (late) issue_dma();
+                load_set(1, wfB, afB);
+                mfma_set(wfA, afA);
+                if (NS == 4) {
+                    load_set(2, wfA, afA);
+                    mfma_set(wfB, afB);
+                    load_set(3, wfB, afB);
+                    mfma_set(wfA, afA);
                 }
             }
         });
     }
+    if (P2P_ABL != 1) mfma_set(wfB, afB);
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -375,7 +412,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
     }
 }
 
-struct BrigPlan { int ok, cbw, ipt, rpt, tiles_per_img, ntiles, nnt, BR, PITCH, BP, npix, npieces, abytes, nkc, rot, slots; size_t shm; };
+struct BrigPlan { int ok, ring, cbw, ipt, rpt, tiles_per_img, ntiles, nnt, BR, PITCH, BP, npix, npieces, abytes, nkc, rot, slots; size_t shm; };
 
 static int brig_enabled() {
     static int v = -1;
@@ -422,7 +459,12 @@ static BrigPlan brig_plan(int op, int dtype, int N, int LH, int LW, int Cg, int 
     p.abytes = (p.npieces + 1) * 1024;         // one spare piece: tap offsets of clamped lanes stay inside the buffer
     p.nkc = (mode == 1 ? 1 : 4) * (C / 32);
     p.slots = p.tiles_per_img;
-    p.shm = 2 * (size_t)p.abytes + 4 * 16384;
+    // weight ring: six stages where LDS allows (more slack between the DMA and its consumer), else four
+    static int ring_env = -1;
+    if (ring_env < 0) { const char* e = getenv("P2P_BRIG_RING"); ring_env = e ? atoi(e) : 0; }
+    p.ring = (ring_env == 4 || ring_env == 6) ? ring_env : 4;      // six stages measured no better than four (r02)
+    if (2 * (size_t)p.abytes + (size_t)p.ring * 16384 > 158 * 1024) p.ring = 4;
+    p.shm = 2 * (size_t)p.abytes + (size_t)p.ring * 16384;
     const size_t epi = 8 * 32 * 144 + 8 * 2 * 64 * 2 * sizeof(float);
     if (p.shm < epi) p.shm = epi;
     if (p.shm > 160 * 1024) return p;
@@ -460,27 +502,31 @@ int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const 
     a.ipt = p.ipt; a.rpt = p.rpt; a.tiles_per_img = p.tiles_per_img; a.ntiles = p.ntiles; a.nnt = p.nnt;
     a.BR = p.BR; a.PITCH = p.PITCH; a.BP = p.BP; a.npix = p.npix; a.npieces = p.npieces;
     a.abytes = p.abytes; a.nkc = p.nkc; a.rot = p.rot;
+    { static int sg = -1; if (sg < 0) { const char* e = getenv("P2P_BRIG_STAGGER"); sg = e ? atoi(e) : 1; } a.stagger = sg; }
     // per-lane gather offsets are 32-bit, counted from the lowest address a block touches (row -1, column -1 of image 0)
     a.in_lo = -((long long)in->row_stride + 1) * in->ld * 2;
     const long long span = ((long long)(N - 1) * in->img_stride + (long long)(op == P2P_OP_P ? LH + 1 : 2 * LH + 1) * in->row_stride +
                             (op == P2P_OP_P ? LW + 1 : 2 * LW + 1)) * in->ld * 2 - a.in_lo;
     P2P_REQUIRE(span < 0xffffffffLL && (long long)16 * a.ncols * a.C * 2 < 0xffffffffLL, "p2p_brig: view larger than 4 GB");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)brig_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)brig_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)brig_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)brig_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
     const dim3 grid((unsigned)(p.ntiles * p.nnt));
     hipStream_t st = (hipStream_t)stream;
-    if (op == P2P_OP_P) {
-        if (p.cbw == 2) brig_kernel<1, 2><<<grid, dim3(512), p.shm, st>>>(a);
-        else brig_kernel<1, 1><<<grid, dim3(512), p.shm, st>>>(a);
-    } else {
-        if (p.cbw == 2) brig_kernel<0, 2><<<grid, dim3(512), p.shm, st>>>(a);
-        else brig_kernel<0, 1><<<grid, dim3(512), p.shm, st>>>(a);
+    const int key = (op == P2P_OP_P ? 4 : 0) + (p.cbw == 2 ? 2 : 0) + (p.ring == 6 ? 1 : 0);
+#define BRIG_GO(M, CB, R)                                                                                                          \
+    do {                                                                                                                           \
+        static bool attr = false;                                                                                                  \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)brig_kernel<M, CB, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        brig_kernel<M, CB, R><<<grid, dim3(512), p.shm, st>>>(a);                                                                  \
+    } while (0)
+    switch (key) {
+        case 0: BRIG_GO(0, 1, 4); break;
+        case 1: BRIG_GO(0, 1, 6); break;
+        case 2: BRIG_GO(0, 2, 4); break;
+        case 3: BRIG_GO(0, 2, 6); break;
+        case 4: BRIG_GO(1, 1, 4); break;
+        case 5: BRIG_GO(1, 1, 6); break;
+        case 6: BRIG_GO(1, 2, 4); break;
+        default: BRIG_GO(1, 2, 6); break;
     }
+#undef BRIG_GO
     return p2p_check_launch("p2p_igemm(block-resident)");
 }
