@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from palette_and_histo_gan_amd import _lib as L          # noqa: E402
+from palette_and_histo_gan_amd import dataset_utils as DU  # noqa: E402
 from palette_and_histo_gan_amd import engine as E        # noqa: E402
 from palette_and_histo_gan_amd import flops as FL        # noqa: E402
 from palette_and_histo_gan_amd import parallel as PAR    # noqa: E402
@@ -38,14 +39,14 @@ MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # TFLOP/s dense, MI355X_MICROARC
 
 
 def synthetic_batch(rank, B, S, palette):
-    from oracle import reference_graph as rg          # generator of the synthetic sprites only (data, not compute)
     rng = np.random.default_rng([47, rank])
-    return rg.synthetic_rgba_batch(rng, B, S, palette_size=palette)
+    return DU.synthetic_rgba_batch(rng, B, S, palette_size=palette)
 
 
 def cpu_baseline(model, S, lambda_l1, lambda_hist, budget_s=20.0):
     """The oracle (torch-CPU f32 restatement of the reference graph, TF 2.9.1 is not installable here) timed
-    on the host cores, on a bounded sample: B=4 batches (the reference's own batch size, configuration.py:24)."""
+    on the host cores, on a bounded sample: B=4 batches (the reference's own batch size, configuration.py:24).
+    The ONLY place where bench.py touches oracle/ (oracle/__init__.py)."""
     from oracle import reference_graph as rg
     # the box's CPU share for one GPU is 16 cores; more threads than that only adds contention in the small
     # (B=4) convolutions (256 threads: 70 s per step, measured)
@@ -150,9 +151,8 @@ def main():
     dtype = L.BF16 if args.dtype == "bf16" else L.F32
     indexed = model == "indexed"
     if indexed:
-        from oracle import reference_graph as rg
         eng = E.Pix2PixEngine(1, 256, "softmax", S, dtype, device=device, seed=47, use_mfma=not args.no_mfma)
-        src, tgt, _pal = rg.synthetic_indexed_batch(np.random.default_rng([47, rank]), B, S, palette)
+        src, tgt, _pal = DU.synthetic_indexed_batch(np.random.default_rng([47, rank]), B, S, palette)
     else:
         eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype, device=device, seed=47, use_mfma=not args.no_mfma)
         src, tgt = synthetic_batch(rank, B, S, palette)
@@ -161,8 +161,8 @@ def main():
 
     def run_step_eager():
         if indexed:
-            return eng.train_step_indexed(src_d, tgt_d, lam_l1, global_batch=B * world, dp=comm)
-        return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, dp=comm)
+            return eng.train_step_indexed(src_d, tgt_d, lam_l1, global_batch=B * world, dp=comm, batch_offset=rank * B)
+        return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, dp=comm, batch_offset=rank * B)
 
     use_graph = world == 1 and args.graph and not indexed
     if use_graph:

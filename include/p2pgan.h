@@ -16,6 +16,10 @@
  *   - dtype selects the storage/MFMA-input type of activations and weight copies: P2P_F32 (parity
  *     mode, exact-f32 MFMA) or P2P_BF16 (throughput mode, bf16 in / f32 accumulate).  Master weights,
  *     gradients, optimizer state, statistics and loss partials are always f32;
+ *   - no entry point reads outside the pixels of the views it is given: where a tile row of an edge layer is wider than
+ *     a pixel (4/8/36/33-channel tensors) the surplus slots re-read bytes of the same pixel.  What a view must provide is
+ *     its zero halo: the stride-2 kernels gather rows/columns -1 .. 2*LH (hi) and -1 .. LH (lo) of every image, the
+ *     stride-1 heads -1 .. H+1 (p2p_view_halo_pixels() = 2 pixels on every side covers all of them);
  *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, no hidden syncs;
  *   - return 0 on success, otherwise a hipError_t / negative argument-check code; the message is
  *     available from p2p_last_error() (thread-local).
@@ -61,6 +65,8 @@ typedef struct {
 
 const char* p2p_last_error(void);
 int p2p_version(void);
+/* Zero halo (pixels on every side of every image) that the gathering kernels rely on; see Conventions. */
+int p2p_view_halo_pixels(void);
 
 /* ---- convolutions -------------------------------------------------------------------------- */
 
@@ -158,8 +164,10 @@ int p2p_wgrad_small_blocks(int dtype, int stride, int N, int LH, int LW, int Cg,
 int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd,
                     const p2p_tensor* hi, const p2p_tensor* lo, float* dw, void* workspace, void* stream);
 
-/* out[c] = sum over all pixels of v[n,y,x,c] (f32): bias gradients of the stride-1 heads. */
-int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, void* stream);
+/* out[c] = sum over all pixels of v[n,y,x,c] (f32): bias gradients of the stride-1 heads.  One partial per workgroup and
+ * channel goes to `workspace` (p2p_view_colsum_workspace_bytes), the partials are added in workgroup order: bit-reproducible. */
+long long p2p_view_colsum_workspace_bytes(int dtype, int N, int H, int W, int C, const p2p_tensor* v);
+int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, float* workspace, void* stream);
 
 /* ---- InstanceNorm + activation + dropout (networks.py:18-19,29-34), fused ---------------------- */
 
@@ -215,9 +223,11 @@ int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor
                    float inv_count, const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g,
                    float* partials, void* stream);
 
-/* fake = tanh(z) written to `fake` view; partials row 0 = inv_count * sum |real - fake| over all C channels. */
+/* fake = tanh(z) written to `fake` view; partials row 0 = inv_count * sum |real - fake| over all C channels.
+ * fake_f32 (may be null): dense f32 [N*H*W][C] copy of tanh(z) before rounding to `dtype` -- the histogram loss reads its
+ * images in f32 in every mode (log-chroma of dark colours does not survive 8 significant bits). */
 int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* real,
-                    const p2p_tensor* fake, float inv_count, float* partials, void* stream);
+                    const p2p_tensor* fake, float inv_count, float* partials, float* fake_f32, void* stream);
 
 /* dz = (g_d + g_extra + lambda_l1*inv_count*sign(fake-real)) * (1 - fake^2) into the haloed view dz. */
 int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
@@ -226,7 +236,9 @@ int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fak
 
 /* ---- RGB-uv histogram + Hellinger loss (histogram.py:4-89, pix2pix_model.py:242-250) ------------------------- */
 
-/* Raw (unnormalised) histogram of the RGB channels of `img` ([-1,1] images): hist[N][3][64][64] f32 with
+/* The histogram entry points take `dtype` = the element type of the IMAGE view they read; the engine always hands them f32
+ * views (the f32 input batch for the real image, p2p_tanh_l1_fwd's fake_f32 for the generated one), also in bf16 mode.
+ * Raw (unnormalised) histogram of the RGB channels of `img` ([-1,1] images): hist[N][3][64][64] f32 with
  * hist[n][c][i][j] = sum_p Iy[p] k(u_p - d_i) k(v_p - d_j) for component c (the reference's (B,64,64,3) tensor
  * transposed and before its division by the per-image total, histogram.py:75-79). */
 int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tensor* img, float* hist, void* stream);
@@ -235,10 +247,11 @@ int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tensor* img, fl
 int p2p_hist_normalize(const float* raw, int N, float* out, void* stream);
 
 /* Per-image totals of both raw histograms and the LOCAL Hellinger sum of squares
- * sq_sum[0] = sum_{n,c,i,j} (sqrt(pred/tot_pred) - sqrt(true/tot_true))^2 (histogram.py:88-89).  Under data
- * parallelism sq_sum is all-reduced (SUM) before the two calls below. */
+ * sq_sum[0] = sum_{n,c,i,j} (sqrt(pred/tot_pred) - sqrt(true/tot_true))^2 (histogram.py:88-89): one partial per image in
+ * sq_part[N], added in image order (bit-reproducible, no float atomics).  Under data parallelism sq_sum is all-reduced
+ * (SUM) before the two calls below. */
 int p2p_hellinger_fwd(const float* hist_true, const float* hist_pred, int N, float* tot_true, float* tot_pred,
-                      float* sq_sum, void* stream);
+                      float* sq_part, float* sq_sum, void* stream);
 /* loss_out[0] = sqrt(sq_sum) / (sqrt(2) * B_global). */
 int p2p_hellinger_finish(const float* sq_sum, float inv_global_batch, float* loss_out, void* stream);
 /* d(coef' * hellinger)/d(fake image) with coef = lambda_hist / (2*sqrt(2)*B_global): writes three f32 slabs
@@ -252,11 +265,14 @@ int p2p_rgbuv_hist_hellinger_bwd(int dtype, int N, int H, int W, const p2p_tenso
 
 /* z: logits view [N][H][W][C]; target: view holding the real palette index of every pixel (as a value of `dtype`).
  * Writes argmax(softmax(z)) (ties -> lowest index) into fake_idx as a value of `dtype`, optionally
- * dz = grad_scale * (softmax(z) - onehot(target)) and the f32 probabilities; loss_out[0] = inv_count * sum CCE,
- * loss_out[1] = inv_count / C * sum |onehot - p|. */
+ * dz = grad_scale * (softmax(z) - onehot(target)) and the f32 probabilities; loss_out[0] = inv_count * sum CCE with
+ * CCE = log(sum_c exp(z_c - max)) - (z_target - max) (the logits form Keras 2.9 uses for a softmax-activated output,
+ * finite for every input), loss_out[1] = inv_count / C * sum |onehot - p|.  loss_part: workspace of
+ * 2 * P2P_SOFTMAX_MAX_BLOCKS floats (one partial per workgroup, summed in workgroup order: bit-reproducible). */
+#define P2P_SOFTMAX_MAX_BLOCKS 8192
 int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* target,
                            const p2p_tensor* fake_idx, float grad_scale, float inv_count, const p2p_tensor* dz,
-                           float* probs_out, float* loss_out, void* stream);
+                           float* probs_out, float* loss_part, float* loss_out, void* stream);
 /* tf.argmax(probs, axis=-1, output_type=int32) on dense f32 probabilities [M][C]; ties -> lowest index. */
 int p2p_argmax_lastdim(const float* probs, long long M, int C, int* out, void* stream);
 
@@ -318,9 +334,11 @@ int p2p_unpack(int dtype, int N, int H, int W, int C, const p2p_tensor* src, flo
 
 /* Bernoulli(0.5) keep mask of Dropout(0.5) (networks.py:31-32): counter-based RNG, one byte per element. */
 int p2p_dropout_mask(unsigned char* mask, long long n, long long seed, long long counter, void* stream);
-/* same with the call counter = counter_dev[0]*16 + salt read on the device. */
+/* same with the call counter = counter_dev[0]*16 + salt read on the device; the random stream is indexed by
+ * elem_offset + i (elem_offset = elements of this layer's mask that belong to the samples in front of the shard, a
+ * multiple of 8), so the ranks of a data-parallel step draw the masks of the single-process global batch. */
 int p2p_dropout_mask_dev(unsigned char* mask, long long n, long long seed, const long long* counter_dev,
-                         long long salt, void* stream);
+                         long long salt, long long elem_offset, void* stream);
 
 #ifdef __cplusplus
 }

@@ -187,8 +187,10 @@ def unet_upsample(x, p, name, mask):
     return _q(torch.relu(x))
 
 
-def unet_generator(p, x, masks, last_activation):
-    """UnetGenerator forward (networks.py:80-98). masks: list of three 0/1 tensors for up1..up3."""
+def unet_generator(p, x, masks, last_activation, aux=None):
+    """UnetGenerator forward (networks.py:80-98). masks: list of three 0/1 tensors for up1..up3.
+    aux (oracle-only, dict): receives "fake_unrounded" = tanh output before the storage rounding (storage_dtype): the
+    engine hands the histogram loss that f32 copy in every mode."""
     inputs = x
     skips = []
     for i in range(1, 7):
@@ -201,7 +203,10 @@ def unet_generator(p, x, masks, last_activation):
         x = torch.cat([x, skip], dim=-1)
     x = conv4x4_s1_bias(x, p["last.kernel"], p["last.bias"])
     if last_activation == "tanh":
-        return _q(torch.tanh(x))
+        y = torch.tanh(x)
+        if aux is not None:
+            aux["fake_unrounded"] = y
+        return _q(y)
     if last_activation == "softmax":
         return torch.softmax(x, dim=-1)
     if last_activation == "logits":          # oracle-only: pre-softmax values for the log-softmax CCE
@@ -316,14 +321,17 @@ def train_step_rgba(Gp, Dp, source, real, masks, lambda_l1, lambda_hist=None, gl
     Both gradients are taken at the same (pre-update) weights; G's gradient flows through D.
     """
     Gl, Dl = _leaf(Gp), _leaf(Dp)
+    real_unrounded = real
     source, real = _q(source), _q(real)
-    fake = unet_generator(Gl, source, masks, "tanh")                     # :67
+    aux = {}
+    fake = unet_generator(Gl, source, masks, "tanh", aux)                # :67
     real_pred = patch_discriminator(Dl, real, source)                     # :69
     fake_pred = patch_discriminator(Dl, fake, source)                     # :70  (fake not detached)
     g_total, adv, l1 = generator_loss(fake_pred, fake, real, lambda_l1)  # :72
     g_loss = [g_total, adv, l1]
     if lambda_hist is not None:                                           # pix2pix_model.py:242-250
-        hist = hellinger_loss(rgbuv_histogram(real), rgbuv_histogram(fake))
+        # f32 arithmetic on f32 images in every storage mode (SURVEY.md 8a A10): identical to (real, fake) without storage_dtype
+        hist = hellinger_loss(rgbuv_histogram(real_unrounded), rgbuv_histogram(aux["fake_unrounded"]))
         g_total = g_total + lambda_hist * hist
         g_loss = [g_total, adv, l1, hist]
     d_total, d_real, d_fake = discriminator_loss(real_pred, fake_pred)    # :75

@@ -36,7 +36,7 @@ SIGNATURES = {
     "p2p_conv_fewout": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_wgemm_edge": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
     "p2p_wgrad_small": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp],
-    "p2p_view_colsum": [_i, _i, _i, _i, _i, _TP, _vp, _vp],
+    "p2p_view_colsum": [_i, _i, _i, _i, _i, _TP, _vp, _vp, _vp],
     "p2p_act_bwd": [_i, _i, _i, _i, _i, _TP, _GP, _GP, _f, _TP, _vp],
     "p2p_weight_prep_pad": [_i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "p2p_wgemm": [_i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
@@ -46,13 +46,13 @@ SIGNATURES = {
     "p2p_colsum_batched": [_vp, _vp, _i, _i, _vp, _vp],
     "p2p_bce_logits": [_i, _i, _i, _i, _i, _TP, _f, _TP, _TP, _vp, _vp],
     "p2p_loss_partials_sum": [_vp, _i, _vp, _vp],
-    "p2p_tanh_l1_fwd": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp],
+    "p2p_tanh_l1_fwd": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp, _vp],
     "p2p_tanh_l1_bwd": [_i, _i, _i, _i, _i, _TP, _TP, _GP, _GP, _f, _TP, _vp],
     "p2p_adam_flat": [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp],
     "p2p_adam_tick": [_vp, _vp, _f, _f, _f, _vp],
     "p2p_adam_flat_dev": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp],
     "p2p_counter_add": [_vp, _ll, _vp],
-    "p2p_dropout_mask_dev": [_vp, _ll, _ll, _vp, _ll, _vp],
+    "p2p_dropout_mask_dev": [_vp, _ll, _ll, _vp, _ll, _ll, _vp],
     "p2p_weight_prep": [_i, _vp, _i, _i, _vp, _vp, _vp],
     "p2p_weight_prep_batched": [_i, _vp, _i, _ll, _vp],
     "p2p_pack_input": [_i, _i, _i, _i, _i, _vp, _i, _TP, _vp],
@@ -63,13 +63,13 @@ SIGNATURES = {
     "p2p_dropout_mask": [_vp, _ll, _ll, _ll, _vp],
     "p2p_rgbuv_hist_fwd": [_i, _i, _i, _i, _TP, _vp, _vp],
     "p2p_hist_normalize": [_vp, _i, _vp, _vp],
-    "p2p_hellinger_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "p2p_hellinger_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "p2p_hellinger_finish": [_vp, _f, _vp, _vp],
     "p2p_rgbuv_hist_hellinger_bwd": [_i, _i, _i, _i, _TP, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
-    "p2p_softmax_cce_argmax": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _f, _TP, _vp, _vp, _vp],
+    "p2p_softmax_cce_argmax": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _f, _TP, _vp, _vp, _vp, _vp],
     "p2p_argmax_lastdim": [_vp, _ll, _i, _vp, _vp],
 }
-SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
+SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int), "p2p_view_halo_pixels": ([], C.c_int),
            "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),
            "p2p_brig_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_brig_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
@@ -80,6 +80,7 @@ SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int),
            "p2p_conv_fewout_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgrad_small_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong),
+           "p2p_view_colsum_workspace_bytes": ([_i, _i, _i, _i, _i, _TP], C.c_longlong),
            "p2p_weight_prep_task_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_longlong)}
 
 

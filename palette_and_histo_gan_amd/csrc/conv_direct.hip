@@ -23,7 +23,8 @@ int p2p_check_launch(const char* what) {
 }
 
 extern "C" const char* p2p_last_error(void) { return g_err; }
-extern "C" int p2p_version(void) { return 1; }
+extern "C" int p2p_version(void) { return 2; }
+extern "C" int p2p_view_halo_pixels(void) { return 2; }
 
 // ---- op G: lo[m][d] = bias[d] + sum_{t,g} hi[pix(m,t)][g] * w[t][g][d] ------------------------------
 template <typename T>
@@ -115,7 +116,7 @@ __global__ void conv_direct_W(int stride, int N, int LH, int LW, int Cg, int Cd,
 // dbias[d] += sum over a chunk of pixels of lo[m][d]: threads = (pixel lane) x (channel), coalesced over channels,
 // pixel lanes folded through LDS, one atomic per channel per workgroup
 template <typename T>
-__global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk) {
+__global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk, float* __restrict__ part = nullptr) {
     __shared__ float red[256];
     const int M = N * LH * LW;                     // < 2^31 pixels
     const int m0 = blockIdx.x * chunk;
@@ -139,7 +140,8 @@ __global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __re
         if (pl == 0 && c0 + c < Cd) {
             float s2 = 0.f;
             for (int i = 0; i < PL; ++i) s2 += red[i * cpt + c];
-            atomicAdd(out + c0 + c, s2);
+            if (part) part[(long long)blockIdx.x * Cd + c0 + c] = s2;        // deterministic form: colsum_partials_kernel adds the workgroups in order
+            else atomicAdd(out + c0 + c, s2);                              // direct (non-MFMA) cross-check path only
         }
     }
 }
@@ -147,7 +149,7 @@ __global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __re
 // Wide-channel form (Cd % 8 == 0, 16-byte aligned view): 16-byte loads, thread = (8-channel vector, pixel lane), a
 // workgroup covers `chunk` pixels; partial sums are combined through LDS and leave as one atomic per channel and workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void view_colsum_vec(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk) {
+__global__ __launch_bounds__(256) void view_colsum_vec(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ part, int chunk) {
     constexpr int VN = 16 / sizeof(T);
     typedef __attribute__((__vector_size__(16))) T vec_t;
     __shared__ float red[256 * 8];
@@ -173,14 +175,14 @@ __global__ __launch_bounds__(256) void view_colsum_vec(int N, int LH, int LW, in
         const int v = c / VN, k = c - v * VN;
         float s2 = 0.f;
         for (int i = 0; i < PL; ++i) s2 += red[(i * nvec + v) * VN + k];
-        atomicAdd(out + c, s2);
+        part[(long long)blockIdx.x * Cd + c] = s2;
     }
 }
 
 // Narrow form (8-channel pixels, Cd <= 8: the bias gradients of the two heads): one whole pixel per lane and step
 // (16 / 32 bytes), 8 running sums per lane, one LDS tree and one atomic per channel and workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void view_colsum_px8(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk) {
+__global__ __launch_bounds__(256) void view_colsum_px8(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ part, int chunk) {
     __shared__ float red[8][256];
     const int M = N * LH * LW;
     const int m0 = blockIdx.x * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
@@ -209,30 +211,51 @@ __global__ __launch_bounds__(256) void view_colsum_px8(int N, int LH, int LW, in
             for (int k = 0; k < 8; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s2];
         __syncthreads();
     }
-    if (threadIdx.x < Cd) atomicAdd(out + threadIdx.x, red[threadIdx.x][0]);
+    if (threadIdx.x < Cd) part[(long long)blockIdx.x * Cd + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// out[c] = sum_b part[b][c], b in workgroup order (one workgroup per channel): bit-reproducible, no float atomics
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 256) s += part[(long long)b * C + c];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[c] = s;
 }
 
 // out[d] = sum over all pixels of v[m][d]  (bias gradients of the two stride-1 heads, networks.py:47-48,75-78)
-extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, void* stream) {
-    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && v && v->ptr && out, "p2p_view_colsum: bad args");
+// pixels per workgroup of the form p2p_view_colsum picks (shared with p2p_view_colsum_workspace_bytes)
+static int view_colsum_chunk(int dtype, int C, const p2p_tensor* v) {
+    if (C <= 8 && v->ld == 8 && ((uintptr_t)v->ptr % 16) == 0) return 4096;     // 256 workgroups at 256 x 64 x 64
+    const int vn = dtype == P2P_BF16 ? 8 : 4;
+    if (C >= 64 && C % vn == 0 && C / vn <= 256 && 256 % (C / vn) == 0 && v->ld % vn == 0 && ((uintptr_t)v->ptr % 16) == 0) return 1024;
+    return C >= 64 ? 256 : 2048;                  // wide pixels: few pixel lanes per workgroup -> more workgroups
+}
+
+extern "C" long long p2p_view_colsum_workspace_bytes(int dtype, int N, int H, int W, int C, const p2p_tensor* v) {
+    if (!v || N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    const long long M = (long long)N * H * W;
+    const int chunk = view_colsum_chunk(dtype, C, v);
+    return ((M + chunk - 1) / chunk) * C * (long long)sizeof(float);
+}
+
+extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_tensor* v, float* out, float* workspace,
+                               void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && v && v->ptr && out && workspace, "p2p_view_colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
-    if (e != hipSuccess) { p2p_set_error("p2p_view_colsum memset: %s", hipGetErrorString(e)); return (int)e; }
     long long M = (long long)N * H * W;
     P2P_REQUIRE(M < (1LL << 31), "p2p_view_colsum: too many pixels");
-    if (C <= 8 && v->ld == 8 && ((uintptr_t)v->ptr % 16) == 0) {
-        const int chunk8 = 4096;                 // 256 workgroups at 256 x 64 x 64
-        P2P_DISPATCH_DTYPE(dtype, (view_colsum_px8<T><<<dim3((unsigned)((M + chunk8 - 1) / chunk8)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunk8)));
-        return p2p_check_launch("p2p_view_colsum");
+    const int chunk = view_colsum_chunk(dtype, C, v);
+    const unsigned nb = (unsigned)((M + chunk - 1) / chunk);
+    if (chunk == 4096) {
+        P2P_DISPATCH_DTYPE(dtype, (view_colsum_px8<T><<<dim3(nb), 256, 0, st>>>(N, H, W, C, make_view(v), workspace, chunk)));
+    } else if (chunk == 1024) {
+        P2P_DISPATCH_DTYPE(dtype, (view_colsum_vec<T><<<dim3(nb), 256, 0, st>>>(N, H, W, C, make_view(v), workspace, chunk)));
+    } else {
+        P2P_DISPATCH_DTYPE(dtype, (view_colsum<T><<<dim3(nb), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunk, workspace)));
     }
-    const int vn = dtype == P2P_BF16 ? 8 : 4;
-    if (C >= 64 && C % vn == 0 && C / vn <= 256 && 256 % (C / vn) == 0 && v->ld % vn == 0 && ((uintptr_t)v->ptr % 16) == 0) {
-        const int chunkv = 1024;                 // pixels per workgroup: 512 workgroups at 128 x 64 x 64
-        P2P_DISPATCH_DTYPE(dtype, (view_colsum_vec<T><<<dim3((unsigned)((M + chunkv - 1) / chunkv)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunkv)));
-        return p2p_check_launch("p2p_view_colsum");
-    }
-    int chunk = C >= 64 ? 256 : 2048;            // wide pixels: few pixel lanes per workgroup -> more workgroups
-    P2P_DISPATCH_DTYPE(dtype, (view_colsum<T><<<dim3((unsigned)((M + chunk - 1) / chunk)), 256, 0, st>>>(N, H, W, C, make_view(v), out, chunk)));
+    colsum_partials_kernel<<<dim3((unsigned)C), 256, 0, st>>>(workspace, (int)nb, C, out);
     return p2p_check_launch("p2p_view_colsum");
 }
 

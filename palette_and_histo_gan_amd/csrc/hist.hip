@@ -92,10 +92,11 @@ __global__ __launch_bounds__(256) void rgbuv_hist_fwd_kernel(int H, int W, TView
 }
 
 // ---- per-image totals, Hellinger partial sum and dL/d(raw histogram) ---------------------------------------
-// totals[n] = sum_{c,i,j} raw[n]  (histogram.py:78);  sq[0] += sum (sqrt(p/Tp) - sqrt(q/Tq))^2  (histogram.py:88-89)
+// totals[n] = sum_{c,i,j} raw[n]  (histogram.py:78);  sq_part[n] = sum (sqrt(p/Tp) - sqrt(q/Tq))^2 of image n (histogram.py:88-89);
+// hellinger_sq_sum_kernel adds the images in index order (deterministic: no float atomics)
 __global__ __launch_bounds__(256) void hellinger_fwd_kernel(const float* __restrict__ h_true, const float* __restrict__ h_pred,
                                                            float* __restrict__ tot_true, float* __restrict__ tot_pred,
-                                                           float* __restrict__ sq) {
+                                                           float* __restrict__ sq_part) {
     __shared__ float red[16];
     const int n = blockIdx.x;
     const int E = 3 * HB * HB;
@@ -111,7 +112,15 @@ __global__ __launch_bounds__(256) void hellinger_fwd_kernel(const float* __restr
         s += d * d;
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) { tot_true[n] = sa; tot_pred[n] = sb; atomicAdd(sq, s); }
+    if (threadIdx.x == 0) { tot_true[n] = sa; tot_pred[n] = sb; sq_part[n] = s; }
+}
+
+__global__ __launch_bounds__(256) void hellinger_sq_sum_kernel(const float* __restrict__ sq_part, int n, float* __restrict__ sq) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += sq_part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) sq[0] = s;
 }
 
 // loss_out[0] = sqrt(sq_global) / (sqrt(2) * B_global)    (histogram.py:88-89)
@@ -275,12 +284,11 @@ extern "C" int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tens
 }
 
 extern "C" int p2p_hellinger_fwd(const float* hist_true, const float* hist_pred, int N, float* tot_true, float* tot_pred,
-                                 float* sq_sum, void* stream) {
-    P2P_REQUIRE(hist_true && hist_pred && N > 0 && tot_true && tot_pred && sq_sum, "p2p_hellinger_fwd: bad args");
+                                 float* sq_part, float* sq_sum, void* stream) {
+    P2P_REQUIRE(hist_true && hist_pred && N > 0 && tot_true && tot_pred && sq_part && sq_sum, "p2p_hellinger_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sq_sum, 0, sizeof(float), st);
-    if (e != hipSuccess) { p2p_set_error("p2p_hellinger_fwd memset: %s", hipGetErrorString(e)); return (int)e; }
-    hellinger_fwd_kernel<<<dim3(N), 256, 0, st>>>(hist_true, hist_pred, tot_true, tot_pred, sq_sum);
+    hellinger_fwd_kernel<<<dim3(N), 256, 0, st>>>(hist_true, hist_pred, tot_true, tot_pred, sq_part);
+    hellinger_sq_sum_kernel<<<1, 256, 0, st>>>(sq_part, N, sq_sum);
     return p2p_check_launch("p2p_hellinger_fwd");
 }
 

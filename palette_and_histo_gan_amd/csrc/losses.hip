@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(int N2, int n_real, Pix
 // fake = tanh(z), L1 partial.  VEC: 4 channels per lane as one 8/16-byte access per view (RGBA head).
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void tanh_l1_fwd_kernel(int N, PixDec dec, int C, TView z, TView real, TView fake, float inv_count,
-                                                          float* __restrict__ partials) {
+                                                          float* __restrict__ partials, float* __restrict__ fake_f32) {
     __shared__ float red[16];
     typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
     const unsigned npix = (unsigned)N * dec.H * dec.W;
@@ -54,18 +54,24 @@ __global__ __launch_bounds__(256) void tanh_l1_fwd_kernel(int N, PixDec dec, int
         if (VEC) {
             const vec4_t zv = *(const vec4_t*)zp, rv = *(const vec4_t*)rp;
             vec4_t fv;
+            f32x4 ff;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                T fq = from_f32<T>(tanhf(to_f32((T)zv[c])));
+                const float t = tanhf(to_f32((T)zv[c]));
+                ff[c] = t;
+                T fq = from_f32<T>(t);
                 fv[c] = fq;
                 acc += fabsf(to_f32((T)rv[c]) - to_f32(fq));
             }
             *(vec4_t*)fp = fv;
+            if (fake_f32) *(f32x4*)(fake_f32 + (long long)p * 4) = ff;      // unrounded copy for the histogram loss
         } else {
             for (int c = 0; c < C; ++c) {
-                T fq = from_f32<T>(tanhf(to_f32(zp[c])));
+                const float t = tanhf(to_f32(zp[c]));
+                T fq = from_f32<T>(t);
                 fp[c] = fq;
                 acc += fabsf(to_f32(rp[c]) - to_f32(fq));
+                if (fake_f32) fake_f32[(long long)p * C + c] = t;
             }
         }
     }
@@ -162,7 +168,7 @@ extern "C" int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const
 }
 
 extern "C" int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* real,
-                               const p2p_tensor* fake, float inv_count, float* partials, void* stream) {
+                               const p2p_tensor* fake, float inv_count, float* partials, float* fake_f32, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_tanh_l1_fwd: bad shape");
     P2P_REQUIRE(z && z->ptr && real && real->ptr && fake && fake->ptr && partials, "p2p_tanh_l1_fwd: null pointer");
     P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_tanh_l1_fwd: too many pixels");
@@ -173,10 +179,10 @@ extern "C" int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_
     const dim3 grid(P2P_LOSS_BLOCKS);
     if (vec) {
         P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_kernel<T, true><<<grid, 256, 0, st>>>(N, PixDec::make(H, W), C, make_view(z), make_view(real),
-                                                                                    make_view(fake), inv_count, partials)));
+                                                                                    make_view(fake), inv_count, partials, fake_f32)));
     } else {
         P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_kernel<T, false><<<grid, 256, 0, st>>>(N, PixDec::make(H, W), C, make_view(z), make_view(real),
-                                                                                     make_view(fake), inv_count, partials)));
+                                                                                     make_view(fake), inv_count, partials, fake_f32)));
     }
     return p2p_check_launch("p2p_tanh_l1_fwd");
 }

@@ -387,12 +387,14 @@ extern "C" int p2p_unpack(int dtype, int N, int H, int W, int C, const p2p_tenso
 // Bernoulli(0.5) keep mask of keras Dropout(0.5) (networks.py:31-32): counter-based (splitmix64 of
 // seed, call counter, element index), one byte per element, 8 elements per hash.
 __global__ void dropout_mask_kernel(unsigned char* __restrict__ mask, long long n, unsigned long long seed,
-                                    unsigned long long counter, const long long* __restrict__ counter_dev) {
+                                    unsigned long long counter, const long long* __restrict__ counter_dev, long long group0) {
     if (counter_dev) counter += (unsigned long long)counter_dev[0] * 16ull;      // device step counter (graph replay)
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (; i * 8 < n; i += stride) {
-        unsigned long long z = seed * 0x9E3779B97F4A7C15ull + counter * 0xD1B54A32D192ED03ull + (unsigned long long)i;
+        // the stream is keyed by the GLOBAL element index (group0 = 8-element groups in front of this shard): an N-rank
+        // data-parallel step draws the masks of the single-process global batch
+        unsigned long long z = seed * 0x9E3779B97F4A7C15ull + counter * 0xD1B54A32D192ED03ull + (unsigned long long)(i + group0);
         z += 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -407,18 +409,19 @@ extern "C" int p2p_dropout_mask(unsigned char* mask, long long n, long long seed
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     dropout_mask_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(mask, n, (unsigned long long)seed,
-                                                                                (unsigned long long)counter, nullptr);
+                                                                                (unsigned long long)counter, nullptr, 0);
     return p2p_check_launch("p2p_dropout_mask");
 }
 
 // same, with the call counter = counter_dev[0] * 16 + salt read on the device (one salt per dropout layer)
 extern "C" int p2p_dropout_mask_dev(unsigned char* mask, long long n, long long seed, const long long* counter_dev,
-                                    long long salt, void* stream) {
+                                    long long salt, long long elem_offset, void* stream) {
     P2P_REQUIRE(mask && n > 0 && counter_dev, "p2p_dropout_mask_dev: bad args");
+    P2P_REQUIRE(elem_offset >= 0 && elem_offset % 8 == 0, "p2p_dropout_mask_dev: elem_offset must be a non-negative multiple of 8");
     long long blocks = (n / 8 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     dropout_mask_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(mask, n, (unsigned long long)seed,
-                                                                                (unsigned long long)salt, counter_dev);
+                                                                                (unsigned long long)salt, counter_dev, elem_offset / 8);
     return p2p_check_launch("p2p_dropout_mask_dev");
 }

@@ -10,13 +10,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// loss_out[0] += inv_count * sum_pixels -log p[target]          (segmentation loss, mean over pixels)
-// loss_out[1] += inv_count/C * sum_pixels sum_c |onehot - p|    (the reported, zero-weighted L1 term, :263,273-278)
+// Per-workgroup partials (deterministic: no float atomics; softmax_loss_sum_kernel adds them in workgroup order):
+//   part[0][b] = inv_count * sum over the workgroup's pixels of -log softmax(z)[target] = log(sum exp(z - max)) - (z_t - max)
+//                (segmentation loss, mean over pixels; the log-sum-exp form of Keras' logits path stays finite when
+//                p_t underflows)
+//   part[1][b] = inv_count/C * sum_pixels sum_c |onehot - p|    (the reported, zero-weighted L1 term, :263,273-278)
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, int W, int C, TView z, TView target,
                                                                 TView fake_idx, float grad_scale, float inv_count,
                                                                 TView dz, float* __restrict__ probs_out,
-                                                                float* __restrict__ loss_out) {
+                                                                float* __restrict__ loss_part) {
     __shared__ float red[16];
     const int lane = threadIdx.x & 63;
     const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -44,6 +47,11 @@ __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, i
             }
         }
         mx = wave_max(mx);
+        const int t = (int)to_f32(((const T*)target.ptr)[target.off(n, y, x)]);
+        float ztm = 0.f;            // z_t - max, taken before the exponentials
+        for (int k = 0; k < per; ++k)
+            if (lane * per + k == t) ztm = v[k] - mx;
+        ztm = wave_sum(ztm);        // exactly one lane holds it
         float s = 0.f;
         for (int k = 0; k < per; ++k) { v[k] = expf(v[k] - mx); s += v[k]; }
         s = wave_sum(s);
@@ -62,14 +70,13 @@ __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, i
             int oi = __shfl_xor(besti, o, 64);
             if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
         }
-        int t = (int)to_f32(((const T*)target.ptr)[target.off(n, y, x)]);
         float pt = 0.f;
         for (int k = 0; k < per; ++k)
             if (lane * per + k == t) pt = v[k];
         pt = wave_sum(pt);          // exactly one lane holds it
         if (lane == 0) {
             ((T*)fake_idx.ptr)[fake_idx.off(n, y, x)] = from_f32<T>((float)besti);
-            seg += -(logf(pt));
+            seg += logf(s) - ztm;
             l1 += 2.f * (1.f - pt);          // sum_c |onehot_c - p_c| = (1 - p_t) + sum_{c != t} p_c
         }
         if (dz.ptr) {
@@ -96,8 +103,20 @@ __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, i
     seg = block_sum(seg, red);
     l1 = block_sum(l1, red);
     if (threadIdx.x == 0) {
-        atomicAdd(loss_out + 0, seg * inv_count);
-        atomicAdd(loss_out + 1, l1 * inv_count / (float)C);
+        loss_part[blockIdx.x] = seg * inv_count;
+        loss_part[gridDim.x + blockIdx.x] = l1 * inv_count / (float)C;
+    }
+}
+
+// loss_out[k] = sum_b part[k][b], b in workgroup order (fixed order -> bit-reproducible)
+__global__ __launch_bounds__(256) void softmax_loss_sum_kernel(const float* __restrict__ part, int nb, float* __restrict__ loss_out) {
+    __shared__ float red[16];
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < nb; b += 256) s += part[k * nb + b];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) loss_out[k] = s;
+        __syncthreads();
     }
 }
 
@@ -108,7 +127,7 @@ __global__ __launch_bounds__(256) void softmax_cce_argmax_kernel(int N, int H, i
 template <typename T>
 __global__ __launch_bounds__(256) void softmax256_kernel(int N, PixDec dec, TView z, TView target, TView fake_idx, float grad_scale,
                                                          float inv_count, TView dz, float* __restrict__ probs_out,
-                                                         float* __restrict__ loss_out) {
+                                                         float* __restrict__ loss_part) {
     constexpr int VN = 16 / sizeof(T);               // elements per 16-byte access
     typedef __attribute__((__vector_size__(16))) T vec_t;
     __shared__ float red[16];
@@ -132,6 +151,11 @@ __global__ __launch_bounds__(256) void softmax256_kernel(int N, PixDec dec, TVie
         for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const int t = (int)to_f32(((const T*)target.ptr)[target.off(n, y, x)]);
+        float zmine = 0.f;          // z_t - max of the lane that owns logit t, taken before the exponentials
+#pragma unroll
+        for (int k = 0; k < 16; ++k) zmine = (k == (t & 15)) ? v[k] - mx : zmine;
+        const float ztm = __shfl(zmine, (lane & 48) + ((t >> 4) & 15), 64);
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { v[k] = expf(v[k] - mx); sum += v[k]; }
@@ -150,14 +174,13 @@ __global__ __launch_bounds__(256) void softmax256_kernel(int N, PixDec dec, TVie
             const int oi = __shfl_xor(besti, o, 64);
             if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
         }
-        const int t = (int)to_f32(((const T*)target.ptr)[target.off(n, y, x)]);
         float mine = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) mine = (k == (t & 15)) ? v[k] : mine;
         const float pt = __shfl(mine, (lane & 48) + ((t >> 4) & 15), 64);
         if (sub == 0) {
             ((T*)fake_idx.ptr)[fake_idx.off(n, y, x)] = from_f32<T>((float)besti);
-            seg += -(logf(pt));
+            seg += logf(sum) - ztm;
             l1 += 2.f * (1.f - pt);
         }
         if (dz.ptr) {
@@ -182,8 +205,8 @@ __global__ __launch_bounds__(256) void softmax256_kernel(int N, PixDec dec, TVie
     seg = block_sum(seg, red);
     l1 = block_sum(l1, red);
     if (threadIdx.x == 0) {
-        atomicAdd(loss_out + 0, seg * inv_count);
-        atomicAdd(loss_out + 1, l1 * inv_count / 256.f);
+        loss_part[blockIdx.x] = seg * inv_count;
+        loss_part[gridDim.x + blockIdx.x] = l1 * inv_count / 256.f;
     }
 }
 
@@ -211,12 +234,10 @@ __global__ void argmax_lastdim_kernel(const float* __restrict__ p, long long M, 
 
 extern "C" int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* target,
                                       const p2p_tensor* fake_idx, float grad_scale, float inv_count, const p2p_tensor* dz,
-                                      float* probs_out, float* loss_out, void* stream) {
+                                      float* probs_out, float* loss_part, float* loss_out, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C <= 512, "p2p_softmax_cce_argmax: bad shape (C <= 512)");
-    P2P_REQUIRE(z && z->ptr && target && target->ptr && fake_idx && fake_idx->ptr && loss_out, "p2p_softmax_cce_argmax: null pointer");
+    P2P_REQUIRE(z && z->ptr && target && target->ptr && fake_idx && fake_idx->ptr && loss_out && loss_part, "p2p_softmax_cce_argmax: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(loss_out, 0, 2 * sizeof(float), st);
-    if (e != hipSuccess) { p2p_set_error("p2p_softmax_cce_argmax memset: %s", hipGetErrorString(e)); return (int)e; }
     TView d;
     if (dz && dz->ptr) d = make_view(dz);
     else { d.ptr = nullptr; d.img = 0; d.row = 0; d.ld = 0; }
@@ -227,10 +248,11 @@ extern "C" int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, con
     if (C == 256 && M < (1LL << 31) && z->ld % vn == 0 && ((uintptr_t)z->ptr % 16) == 0 &&
         (!dz || !dz->ptr || (dz->ld % vn == 0 && ((uintptr_t)dz->ptr % 16) == 0)) && (!probs_out || ((uintptr_t)probs_out % 16) == 0)) {
         long long b16 = (M + 15) / 16;               // 16 pixel groups per 256-thread workgroup
-        if (b16 > 8192) b16 = 8192;
+        if (b16 > P2P_SOFTMAX_MAX_BLOCKS) b16 = P2P_SOFTMAX_MAX_BLOCKS;
         P2P_DISPATCH_DTYPE(dtype, (softmax256_kernel<T><<<dim3((unsigned)b16), 256, 0, st>>>(
                                       N, PixDec::make(H, W), make_view(z), make_view(target), make_view(fake_idx), grad_scale, inv_count,
-                                      d, probs_out, loss_out)));
+                                      d, probs_out, loss_part)));
+        softmax_loss_sum_kernel<<<1, 256, 0, st>>>(loss_part, (int)b16, loss_out);
         return p2p_check_launch("p2p_softmax_cce_argmax");
     }
     if (C == 256)
@@ -238,7 +260,8 @@ extern "C" int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, con
                     "p2p_softmax_cce_argmax: 256-way views must be 4-channel aligned");
     P2P_DISPATCH_DTYPE(dtype, (softmax_cce_argmax_kernel<T><<<dim3((unsigned)blocks), 256, 0, st>>>(
                                   N, H, W, C, make_view(z), make_view(target), make_view(fake_idx), grad_scale, inv_count, d,
-                                  probs_out, loss_out)));
+                                  probs_out, loss_part)));
+    softmax_loss_sum_kernel<<<1, 256, 0, st>>>(loss_part, (int)blocks, loss_out);
     return p2p_check_launch("p2p_softmax_cce_argmax");
 }
 

@@ -7,9 +7,9 @@
 // read ds_read_b64_tr_b16, for f32 (v_mfma_f32_32x32x2_f32, one pixel per lane) by a plain ds_read_b32.
 // One workgroup = one tap x BG x BD output tile x one chunk of the pixel range; partial tiles go to f32
 // slabs [msplit][16][Cg][Cd] and are summed in a fixed order (deterministic, no float atomics).
-// Channel counts that are not tile multiples (edge layers: 4/8/36/33 channels, 1..4 output channels) are
-// handled by letting a tile row run past the pixel's channels into the following pixels' bytes (finite
-// values of the same buffer) and masking the store to g < Cg, d < Cd.
+// Channel counts that are not tile multiples (edge layers: 4/8/36/33 channels, 1..4 output channels): the
+// tile-row slots beyond the pixel's bytes re-read the pixel's first 16-byte chunk (never another pixel, never
+// past the view) and the store is masked to g < Cg, d < Cd.
 #include "p2p_common.hpp"
 
 struct WgemmArgs {
@@ -85,7 +85,12 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
             // 32-bit pixel index (views of < 2^31 pixels, checked on the host), then ONE 64-bit multiply-add: the 64-bit
             // products of the first version made the staging VALU-bound (25 % of the wave cycles, r01 SQ counters)
             const int pix = n * hi_img32 + (s * y + kh - 1) * a.hi_row + (s * x + kw - 1);
-            const char* src = a.hi + (long long)pix * hi_pixB + (g0 * ESZ + chunk * 16);
+            // a tile row wider than the pixel (edge layers) must not leave the pixel: those slots only feed masked outputs,
+            // so they re-read the pixel's first chunk (in bounds whatever lies behind the view; r01 read on into the
+            // following pixels and, for the last pixel of a small map, past the allocation)
+            int coff = g0 * ESZ + chunk * 16;
+            if (coff >= hi_pixB) coff = 0;
+            const char* src = a.hi + (long long)pix * hi_pixB + coff;
             glds16w(src, buf + inst * 1024);
         }
 #pragma unroll
@@ -97,12 +102,14 @@ __global__ __launch_bounds__(WM * WN * 64) void wgemm_kernel(WgemmArgs a) {
             int chunk = (lg << 2) | (sl & 3);
             int m = mb + row;
             const char* src;
+            int coff = d0 * ESZ + chunk * 16;
+            if (coff >= lo_pixB) coff = 0;
             if (m < mend) {
                 int x = m & (a.LW - 1), y = (m >> a.lgLW) & (a.LH - 1), n = m >> (a.lgLW + a.lgLH);
                 const int pix = n * lo_img32 + y * a.lo_row + x;
-                src = a.lo + (long long)pix * lo_pixB + (d0 * ESZ + chunk * 16);
+                src = a.lo + (long long)pix * lo_pixB + coff;
             } else {
-                src = a.lo + (((long long)(-1) * a.lo_row - 1) * a.lo_ld + d0) * ESZ + chunk * 16;   // halo row -1: zeros
+                src = a.lo + ((long long)(-1) * a.lo_row - 1) * lo_pixB + coff;   // halo row -1: zeros
             }
             glds16w(src, buf + A_BYTES + inst * 1024);
         }

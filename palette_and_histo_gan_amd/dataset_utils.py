@@ -93,3 +93,35 @@ def synthetic_indexed_ds(n_images, batch_size=BATCH_SIZE, img_size=IMG_SIZE, pal
     src, tgt = draw(), draw()
     return Dataset.from_batches((src[i:i + batch_size], tgt[i:i + batch_size], pal[i:i + batch_size])
                                 for i in range(0, n_images, batch_size))
+
+
+def synthetic_rgba_batch(rng, batch, img_size, palette_size=None):
+    """One sprite-like RGBA batch (source, target) in [-1,1] for benchmarks: per image a palette of P
+    opaque colours (P = palette_size, or uniform in 10..54 like the shipped sprites), pixels transparent (0,0,0,0) with
+    probability 0.835, source and target share the palette but draw their pixels independently
+    (dataset_utils.py:11-20,39-48 value contract)."""
+    src = np.zeros((batch, img_size, img_size, 4), np.uint8)
+    tgt = np.zeros_like(src)
+    for b in range(batch):
+        P = palette_size or int(rng.integers(10, 55))
+        pal = np.concatenate([rng.integers(0, 256, size=(P, 3)), np.full((P, 1), 255)], axis=1).astype(np.uint8)
+        for out in (src, tgt):
+            opaque = rng.random((img_size, img_size)) >= 0.835
+            idx = rng.integers(0, P, size=(img_size, img_size))
+            out[b] = np.where(opaque[..., None], pal[idx], 0)
+    to_f = lambda a: (a.astype(np.float32) / 127.5 - 1.0)
+    return to_f(src), to_f(tgt)
+
+
+def synthetic_indexed_batch(rng, batch, img_size, palette_size=24):
+    """One indexed batch (source_idx, target_idx, palette): int32 (B,S,S,1) with 0 (transparent black) with probability 0.835,
+    else uniform in 1..P-1; palette (B,256,4) padded with INVALID_INDEX_COLOR (configuration.py:31-32, io_utils.py:50-63)."""
+    def draw():
+        opaque = rng.random((batch, img_size, img_size, 1)) >= 0.835
+        idx = rng.integers(1, palette_size, size=(batch, img_size, img_size, 1))
+        return np.where(opaque, idx, 0).astype(np.int32)
+    pal = np.tile(np.array(INVALID_INDEX_COLOR, np.int32), (batch, MAX_PALETTE_SIZE, 1))
+    pal[:, :palette_size, :3] = rng.integers(0, 256, size=(batch, palette_size, 3))
+    pal[:, :palette_size, 3] = 255
+    pal[:, 0] = 0
+    return draw(), draw(), pal

@@ -68,8 +68,8 @@ class HaloBuf:
     def __init__(self, n, h, w, c, dtype, device):
         self.n, self.h, self.w, self.c, self.dtype = n, h, w, c, dtype
         self.hp, self.wp = h + 2 * HALO, w + 2 * HALO
-        # 512 bytes of zeroed tail slack: the edge-layer weight-gradient tiles read whole 64/128-byte rows from pixels
-        # that hold fewer channels, i.e. up to 112 bytes past the last halo pixel of the last image
+        # No kernel reads outside the pixels of a view any more (include/p2pgan.h, Conventions; round 1's wgemm tiles ran
+        # past short pixels); the 256 zeroed tail elements stay as a guard band.
         numel = n * self.hp * self.wp * c
         self._flat = torch.zeros(numel + 256, dtype=_torch_dtype(dtype), device=device)
         self.t = self._flat[:numel].view(n, self.hp, self.wp, c)
@@ -265,6 +265,7 @@ class Pix2PixEngine:
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
         self._dp = None             # parallel.DataParallel of the step in flight
+        self._batch_offset = 0      # samples of the global batch in front of this rank's shard (keys the dropout stream)
         self.use_conv_fewout = os.environ.get("P2P_CONV_FEWOUT", "1") != "0"    # 1..4-output heads: tap-major GEMM + shifted sum
         self.use_conv_strip = os.environ.get("P2P_CONV_STRIP", "1") != "0"      # up6 (32 <-> 128 channels): LDS strip, weights in registers
         self.use_conv_fewin = os.environ.get("P2P_CONV_FEWIN", "1") != "0"      # 8-channel inputs: weights in registers, strip in LDS
@@ -602,7 +603,7 @@ class Pix2PixEngine:
             if nb > 0 and nb * 16 * cg * cd <= P["wws"].numel():
                 L.call("p2p_wgrad_small", self.dtype, stride, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), dw, _p(P["wws"]), _stream())
                 if dbias is not None:
-                    L.call("p2p_view_colsum", self.dtype, N, lh, lh, cd, C.byref(lo), dbias, _stream())
+                    self._colsum(P, N, lh, cd, lo, dbias)
                 return
         ms = self._msplit(N, lh, cg, cd)
         ws = _p(P["wws"]) if ms > 1 else NULL
@@ -611,7 +612,17 @@ class Pix2PixEngine:
         else:
             L.call("p2p_wgemm_edge", self.dtype, stride, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), dw, ms, ws, _stream())
         if dbias is not None:
-            L.call("p2p_view_colsum", self.dtype, N, lh, lh, cd, C.byref(lo), dbias, _stream())
+            self._colsum(P, N, lh, cd, lo, dbias)
+
+    def _colsum(self, P, N, lh, cd, lo, dbias):
+        """bias gradient = column sum of the layer's output gradient (deterministic: per-workgroup partials in a workspace
+        of its own -- the call runs on the weight-gradient stream)"""
+        need = L.lib().p2p_view_colsum_workspace_bytes(self.dtype, N, lh, lh, cd, C.byref(lo)) // 4
+        key = ("cs_ws", cd)
+        ws = P.get(key)
+        if ws is None or ws.numel() < need:
+            ws = P[key] = torch.empty(max(need, 16), dtype=torch.float32, device=self.device)
+        L.call("p2p_view_colsum", self.dtype, N, lh, lh, cd, C.byref(lo), dbias, _p(ws), _stream())
 
     def _nsplit(self, N, res, c, bwd=False):
         """Pixel-range splits of the InstanceNorm kernels.  Measured on MI355X (B=256): the split form re-reads the
@@ -696,7 +707,8 @@ class Pix2PixEngine:
                 for i, drop in enumerate(UP_DROPOUT, start=1):
                     if drop:
                         m = P["mask"][i]
-                        L.call("p2p_dropout_mask_dev", _p(m), m.numel(), self.seed, _p(self.mask_counter_dev), i, _stream())
+                        L.call("p2p_dropout_mask_dev", _p(m), m.numel(), self.seed, _p(self.mask_counter_dev), i,
+                               self._batch_offset * (m.numel() // P["B"]), _stream())
             if apply_update:
                 L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
                 for store in (self.G, self.D):
@@ -740,7 +752,8 @@ class Pix2PixEngine:
                         torch.cuda.current_stream().wait_event(P["early_ev"])
                         P["early_ev"] = None
                 else:       # Bernoulli(0.5) keep mask (networks.py:31-32), counter-based device RNG
-                    L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self.seed, _p(self.mask_counter_dev), i, _stream())
+                    L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self.seed, _p(self.mask_counter_dev), i,
+                           self._batch_offset * (mask.numel() // B), _stream())
             self._norm_fwd(P, B, 2 * lh, f, P["ru"][i], rk, self.G.p(f"up{i}.gamma"), self.G.p(f"up{i}.beta"),
                            L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i])
             lo_view = c[i].view()
@@ -770,7 +783,7 @@ class Pix2PixEngine:
 
     # ------------------------------------------------------------------ train step (RGBA models)
     def train_step_rgba(self, source, real, lambda_l1, lambda_hist=None, masks=None, global_batch=None,
-                        apply_update=True, dp=None):
+                        apply_update=True, dp=None, batch_offset=0):
         """Pix2PixModel.train_step / Pix2PixHistogramModel (pix2pix_model.py:62-89,242-250).
         Returns a device tensor [g_total, g_adv, g_l1, g_hist, d_total, d_real, d_fake] (f32)."""
         B = int(source.shape[0])
@@ -778,6 +791,7 @@ class Pix2PixEngine:
         S, ic = self.S, self.in_ch
         Bg = global_batch or B
         self._dp = dp
+        self._batch_offset = int(batch_offset)
         src_t, real_t = self._to_device(source, ic, B), self._to_device(real, ic, B)
         if ic == 4 and self.src_ch == 8 and self.dcat_ch == 8:
             # source and target in one launch, whole 16-byte pixels (networks.py:45,92-94)
@@ -788,13 +802,16 @@ class Pix2PixEngine:
             self._pack_source(P, src_t, with_disc=True)
             self._pack(P, real_t, P["dcat"].view(coff=0), ic)
         if lambda_hist is not None:
-            self._hist_real_early(P, B)
+            self._hist_real_early(P, B, real_t)
         self._early_side(P, masks, apply_update)
         self.generator_forward(P, masks)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
         inv_l1 = 1.0 / (Bg * S * S * self.out_ch)
+        if lambda_hist is not None:
+            self._hist_buffers(P, B)
         L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
-               C.byref(fake_view), inv_l1, _p(self.loss_part, 3 * 256), _stream())
+               C.byref(fake_view), inv_l1, _p(self.loss_part, 3 * 256), _p(P["fake32"]) if lambda_hist is not None else NULL,
+               _stream())
         g_extra = None
         if lambda_hist is not None:
             # the histogram loss only needs `fake`: its kernels (f32 MFMA, ~1.8 ms at B=256) run on the side stream,
@@ -892,6 +909,33 @@ class Pix2PixEngine:
         self.step_count += 1
         return out[:7]
 
+    def train_step_empty(self, lambda_l1, lambda_hist=None, lambda_aux=None, dp=None, apply_update=True):
+        """The step of a rank whose shard of the global batch is empty (global batch smaller than the world: the ragged
+        tail of an epoch, dataset_utils.py:223 has no drop_remainder): contributes zero gradients and zero loss partials,
+        issues the SAME collectives in the same order as a rank with samples -- the Hellinger scalar first (histogram model),
+        then the gradient buckets, then the tail with the loss slots -- and applies the same Adam update."""
+        self._dp = dp
+        self._grad_all.zero_()
+        if dp is not None:
+            if lambda_hist is not None:
+                if getattr(self, "_zero_scalar", None) is None:
+                    self._zero_scalar = torch.zeros(1, dtype=torch.float32, device=self.device)
+                self._zero_scalar.zero_()
+                dp.allreduce_scalar_sum(self._zero_scalar)
+            for lo_e, hi_e in self.G.buckets[:-1]:
+                dp.allreduce_async(self.G.grads[lo_e:hi_e])
+        self._reduce_tail()
+        if apply_update:
+            self.apply_adam()
+        out = torch.empty(8, dtype=torch.float32, device=self.device)
+        if self.head == "softmax":
+            L.call("p2p_finish_losses", _p(self.losses), 5, 6, 0.0, float(lambda_aux or 0.0), _p(out), _stream())
+        else:
+            L.call("p2p_finish_losses", _p(self.losses), 4 if lambda_hist is not None else -1, 3, float(lambda_l1),
+                   float(lambda_hist) if lambda_hist is not None else 0.0, _p(out), _stream())
+        self.step_count += 1
+        return out[:7]
+
     def _adam_head(self, apply_update):
         """Single-GPU steps: the main stream finishes the backward pass ~70 us before the weight-gradient stream does (the
         last layers' weight gradients are issued last).  Adam on the part of the generator's flat buffer whose gradients
@@ -935,20 +979,21 @@ class Pix2PixEngine:
         all-reduced between the forward and the backward kernels."""
         S = self.S
         self._hist_buffers(P, B)
-        real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
-        if not P.get("h_real_done"):
-            L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(real_view), _p(P["h_real"]), _stream())
+        # both images are read in f32 in every mode: the real one from the f32 input batch (_hist_real_early), the fake one
+        # from the unrounded copy that p2p_tanh_l1_fwd wrote (histogram.py:53-79 is f32 arithmetic; SURVEY.md 8a A10)
+        fake_view = L.Tensor(P["fake32"].data_ptr(), S * S, S, 4)
+        assert P.get("h_real_done"), "the real histogram is taken by _hist_real_early"
         P["h_real_done"] = False
-        L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(fake_view), _p(P["h_fake"]), _stream())
+        L.call("p2p_rgbuv_hist_fwd", L.F32, B, S, S, C.byref(fake_view), _p(P["h_fake"]), _stream())
         L.call("p2p_hellinger_fwd", _p(P["h_real"]), _p(P["h_fake"]), B, _p(P["h_tot"][0]), _p(P["h_tot"][1]),
-               _p(P["h_sq"]), _stream())
+               _p(P["h_sqp"]), _p(P["h_sq"]), _stream())
         if hist_allreduce is not None:
             hist_allreduce(P["h_sq"][:1])
         # every rank holds the GLOBAL loss after the exchange; it records its B/Bg share so that the SUM all-reduce
         # of the loss scalars (like the element-mean losses) yields the global value
         L.call("p2p_hellinger_finish", _p(P["h_sq"]), (1.0 / Bg) * (B / Bg), _p(self.losses, 4), _stream())
         coef = float(lambda_hist) / (2.0 * math.sqrt(2.0) * Bg)
-        L.call("p2p_rgbuv_hist_hellinger_bwd", self.dtype, B, S, S, C.byref(fake_view), _p(P["h_real"]), _p(P["h_fake"]),
+        L.call("p2p_rgbuv_hist_hellinger_bwd", L.F32, B, S, S, C.byref(fake_view), _p(P["h_real"]), _p(P["h_fake"]),
                _p(P["h_tot"][0]), _p(P["h_tot"][1]), _p(P["h_sq"]), coef, _p(P["h_gh"]), _p(P["h_dimg"]), _stream())
         return L.GSrc(P["h_dimg"].data_ptr(), 2, 3, B * S * S * 4, 4, 0)
 
@@ -961,15 +1006,19 @@ class Pix2PixEngine:
         P["h_gh"] = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
         P["h_tot"] = torch.empty((2, B), dtype=torch.float32, device=dev)
         P["h_sq"] = torch.zeros(4, dtype=torch.float32, device=dev)
+        P["h_sqp"] = torch.zeros(B, dtype=torch.float32, device=dev)      # per-image partials of the Hellinger sum
         P["h_dimg"] = torch.empty(3 * B * S * S * 4, dtype=torch.float32, device=dev)
+        P["fake32"] = torch.empty(B * S * S * 4, dtype=torch.float32, device=dev)      # tanh output before rounding to the activation dtype
 
-    def _hist_real_early(self, P, B):
-        """histogram of the REAL image (no dependence on the generator): issued on the histogram stream right after the
-        batch is packed, so its f32-MFMA work overlaps the generator forward."""
+    def _hist_real_early(self, P, B, real_t):
+        """histogram of the REAL image (no dependence on the generator), read from the dense f32 input batch: issued on the
+        histogram stream at the start of the step, so its f32-MFMA work overlaps the generator forward."""
         self._hist_buffers(P, B)
+        S = self.S
+        P["h_real_src"] = real_t           # keep the batch tensor alive until the kernel has run
         self.side_hist.fork()
         with self.side_hist.run():
-            L.call("p2p_rgbuv_hist_fwd", self.dtype, B, self.S, self.S, C.byref(P["dcat"].view(coff=0)), _p(P["h_real"]), _stream())
+            L.call("p2p_rgbuv_hist_fwd", L.F32, B, S, S, C.byref(L.Tensor(real_t.data_ptr(), S * S, S, 4)), _p(P["h_real"]), _stream())
         P["h_real_done"] = True
 
     def rgbuv_histogram(self, image):
@@ -978,17 +1027,15 @@ class Pix2PixEngine:
         B = int(image.shape[0])
         S = self.S
         img_t = self._to_device(image, 4, B)
-        buf = HaloBuf(B, S, S, 8, self.dtype, self.device)
-        L.call("p2p_pack_input", self.dtype, B, S, S, 4, _p(img_t), 0, C.byref(buf.view()), _stream())
         raw = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=self.device)
-        L.call("p2p_rgbuv_hist_fwd", self.dtype, B, S, S, C.byref(buf.view()), _p(raw), _stream())
+        L.call("p2p_rgbuv_hist_fwd", L.F32, B, S, S, C.byref(L.Tensor(img_t.data_ptr(), S * S, S, 4)), _p(raw), _stream())
         out = torch.empty((B, 64, 64, 3), dtype=torch.float32, device=self.device)
         L.call("p2p_hist_normalize", _p(raw), B, _p(out), _stream())
         return out
 
     # ------------------------------------------------------------------ train step (indexed model)
     def train_step_indexed(self, source_idx, real_idx, lambda_segmentation, masks=None, global_batch=None,
-                           apply_update=True, dp=None):
+                           apply_update=True, dp=None, batch_offset=0):
         """Pix2PixIndexedModel.train_step (pix2pix_model.py:295-325).  source/real: int (B,S,S,1) palette indices.
         The discriminator sees un-normalised index images and the argmax blocks every gradient from D to G, so the
         generator learns from lambda_seg * CCE only (lambda_l1 is hard-wired to 0, :263).
@@ -999,6 +1046,7 @@ class Pix2PixEngine:
         S = self.S
         Bg = global_batch or B
         self._dp = dp
+        self._batch_offset = int(batch_offset)
         src_t = self._to_device(source_idx, 1, B, is_int=True)
         real_t = self._to_device(real_idx, 1, B, is_int=True)
         self._pack_source(P, src_t, with_disc=True)
@@ -1009,7 +1057,7 @@ class Pix2PixEngine:
         inv_pix = 1.0 / (Bg * S * S)
         L.call("p2p_softmax_cce_argmax", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
                C.byref(fake_view), float(lambda_segmentation) * inv_pix, inv_pix, C.byref(P["dz"].view()), NULL,
-               _p(self.losses, 5), _stream())
+               _p(self._softmax_part()), _p(self.losses, 5), _stream())
         self.discriminator_forward(P, 2 * B)
         h2 = S // 2
         L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), 1.0 / (Bg * h2 * h2),
@@ -1028,6 +1076,12 @@ class Pix2PixEngine:
         L.call("p2p_finish_losses", _p(self.losses), 5, 6, 0.0, float(lambda_segmentation), _p(out), _stream())
         self.step_count += 1
         return out[:7]
+
+    def _softmax_part(self):
+        """workspace of p2p_softmax_cce_argmax: one (CCE, L1) partial per workgroup (include/p2pgan.h)"""
+        if getattr(self, "_sm_part", None) is None:
+            self._sm_part = torch.zeros(2 * 8192, dtype=torch.float32, device=self.device)
+        return self._sm_part
 
     def discriminate(self, target, source):
         """discriminator([target, source], training=True) (pix2pix_model.py:69-70): f32 device logits (B,S/2,S/2,1)."""
@@ -1055,7 +1109,7 @@ class Pix2PixEngine:
         fake_view = P["dcat"].view(coff=0, n0=B)
         probs = torch.empty((B, S, S, self.out_ch), dtype=torch.float32, device=self.device)
         L.call("p2p_softmax_cce_argmax", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(fake_view),
-               C.byref(fake_view), 0.0, 0.0, None, _p(probs), _p(self.losses, 14), _stream())
+               C.byref(fake_view), 0.0, 0.0, None, _p(probs), _p(self._softmax_part()), _p(self.losses, 14), _stream())
         idx = torch.empty((B * S * S,), dtype=torch.int32, device=self.device)
         L.call("p2p_argmax_lastdim", _p(probs), B * S * S, self.out_ch, _p(idx), _stream())
         idx = idx.view(B, S, S, 1)
@@ -1116,7 +1170,7 @@ class Pix2PixEngine:
         fake_view = P["dcat"].view(coff=0, n0=B)
         # tanh through the loss kernel (its L1 output lands in a scratch slot and is ignored)
         L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(fake_view),
-               C.byref(fake_view), 0.0, _p(self.loss_part, 4 * 256), _stream())
+               C.byref(fake_view), 0.0, _p(self.loss_part, 4 * 256), NULL, _stream())
         out = torch.empty((B, S, S, self.out_ch), dtype=torch.float32, device=self.device)
         L.call("p2p_unpack", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), _p(out), _stream())
         return out

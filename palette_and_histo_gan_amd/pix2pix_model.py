@@ -5,10 +5,22 @@
     Pix2PixHistogramModel(..., lambda_l1, lambda_histogram)
     Pix2PixIndexedModel(train_ds, test_ds, model_name, architecture_name, lambda_segmentation=0.5)
 
-train_step(batch, step, update_steps) keeps the reference's contract (one optimisation step of both networks with
-gradients taken at the same pre-update weights, scalars logged at step // update_steps) and additionally RETURNS
-(g_loss_tuple, d_loss_tuple) as device scalars, and tolerates summary_writer=None.
-Extra keyword arguments (dtype, img_size, device, data_parallel) are build-added; defaults reproduce the reference.
+The constructor follows the reference's (pix2pix_model.py:12-36): create_generator() / create_discriminator() with the
+reference's builder signatures, `loss_object`, two Adam(0.0002, beta_1=0.5) optimizers, `checkpoint`,
+`checkpoint_manager`.  train_step(batch, step, update_steps) keeps the reference's contract (one optimisation step of
+both networks with gradients taken at the same pre-update weights, scalars logged at step // update_steps) and
+additionally RETURNS (g_loss_tuple, d_loss_tuple) as device scalars, and tolerates summary_writer=None.
+
+The step is FUSED: generator_loss / discriminator_loss of the classes below are evaluated by the HIP kernels inside
+engine.train_step_* together with their gradients (there is no autograd tape here).  The methods exist with the
+reference's signatures for standalone evaluation, but a SUBCLASS that overrides one of them cannot change the fused step;
+train_step detects that and raises instead of silently ignoring the override.
+Extra keyword arguments (dtype, img_size, device, data_parallel, seed) are build-added; defaults reproduce the reference.
+
+Data parallelism (build-added): with `data_parallel`, every rank is handed the same GLOBAL batch (same
+dataset, same order) and takes its contiguous shard (parallel.shard_bounds); loss denominators use the global batch, the
+dropout stream is keyed by the global sample index, gradients are summed over ranks.  Ragged global batches and ranks with
+an empty shard are handled.
 """
 import torch
 
@@ -17,7 +29,47 @@ from . import histogram as _histogram  # noqa: F401  (module parity with the ref
 from .configuration import IMG_SIZE, MAX_PALETTE_SIZE
 from .engine import Pix2PixEngine
 from .networks import PatchDiscriminator, UnetGenerator
-from .side2side_model import CheckpointManager, S2SModel
+from .parallel import shard_bounds
+from .side2side_model import Checkpoint, CheckpointManager, S2SModel
+
+
+class BinaryCrossentropy:
+    """tf.keras.losses.BinaryCrossentropy(from_logits=True) (pix2pix_model.py:19) for standalone evaluation: mean over all
+    elements of max(x,0) - x*z + log1p(exp(-|x|))."""
+
+    def __init__(self, from_logits=True):
+        if not from_logits:
+            raise NotImplementedError("the reference only uses from_logits=True")
+
+    def __call__(self, y_true, y_pred):
+        x = torch.as_tensor(y_pred, dtype=torch.float32)
+        z = torch.as_tensor(y_true, dtype=torch.float32).to(x.device)
+        return torch.nn.functional.binary_cross_entropy_with_logits(x, z)
+
+
+class CategoricalCrossentropy:
+    """tf.keras.losses.CategoricalCrossentropy(from_logits=False) (pix2pix_model.py:265) on probabilities: Keras' fallback
+    formula p /= sum p; p = clip(p, 1e-7, 1 - 1e-7); mean over pixels of -sum t log p."""
+
+    def __call__(self, y_true, y_pred):
+        p = torch.as_tensor(y_pred, dtype=torch.float32)
+        t = torch.as_tensor(y_true, dtype=torch.float32).to(p.device)
+        p = p / p.sum(-1, keepdim=True)
+        p = p.clamp(1e-7, 1.0 - 1e-7)
+        return -(t * p.log()).sum(-1).mean()
+
+
+class Adam:
+    """tf.keras.optimizers.Adam(learning_rate, beta_1) as the reference constructs it (pix2pix_model.py:28-29): the
+    hyper-parameters live here, the moments and the step count in the engine's flat buffers (engine.ParamStore)."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+        self._store = None
+
+    @property
+    def iterations(self):
+        return 0 if self._store is None else self._store.t
 
 
 class Pix2PixModel(S2SModel):
@@ -28,39 +80,63 @@ class Pix2PixModel(S2SModel):
         self._dtype = {"bf16": L.BF16, "f32": L.F32}[dtype] if isinstance(dtype, str) else dtype
         self._img_size, self._device, self._seed = img_size, device, seed
         self.data_parallel = data_parallel
-        self.engine = self.create_engine()
+
         self.generator = self.create_generator()
         self.discriminator = self.create_discriminator()
+        self.loss_object = BinaryCrossentropy(from_logits=True)
+        self.generator_optimizer = Adam(0.0002, beta_1=0.5)
+        self.discriminator_optimizer = Adam(0.0002, beta_1=0.5)
+        self.engine = self.create_engine()
+
         print(f"Generator: {self.generator.name} with {self.generator.count_params():,} parameters")
         print(f"Discriminator: {self.discriminator.name} with {self.discriminator.count_params():,} parameters")
-        # tf.keras.optimizers.Adam(0.0002, beta_1=0.5) x2 live inside the engine (pix2pix_model.py:28-29)
-        self.generator_optimizer = self.engine.G
-        self.discriminator_optimizer = self.engine.D
-        self.checkpoint_manager = CheckpointManager(self.engine, self.checkpoint_dir, max_to_keep=1)
+
+        self.checkpoint = Checkpoint(generator_optimizer=self.generator_optimizer,
+                                     discriminator_optimizer=self.discriminator_optimizer,
+                                     generator=self.generator, discriminator=self.discriminator, engine=self.engine)
+        self.checkpoint_manager = CheckpointManager(self.checkpoint, directory=self.checkpoint_dir, max_to_keep=1)
+        self._hooks_checked = False
 
     # -- construction hooks (pix2pix_model.py:38-42) ------------------------------------------------------------
-    def create_engine(self):
-        return Pix2PixEngine(4, 4, "tanh", self._img_size, self._dtype, device=self._device, seed=self._seed)
-
     def create_generator(self):
-        return UnetGenerator(self.engine)
+        return UnetGenerator(4, 4, "tanh")
 
     def create_discriminator(self):
-        return PatchDiscriminator(self.engine)
+        return PatchDiscriminator(4)
+
+    def create_engine(self):
+        """build-added: one device engine for both networks, from the architecture the two builders recorded"""
+        g, d = self.generator, self.discriminator
+        if d.input_channels != g.input_channels:
+            raise ValueError("the discriminator sees [target, source] images of the generator's input channel count")
+        eng = Pix2PixEngine(g.input_channels, g.output_channels, g.last_activation, self._img_size, self._dtype,
+                            device=self._device, seed=self._seed)
+        go, do = self.generator_optimizer, self.discriminator_optimizer
+        if (go.learning_rate, go.beta_1, go.beta_2, go.epsilon) != (do.learning_rate, do.beta_1, do.beta_2, do.epsilon):
+            raise NotImplementedError("both optimizers share one set of Adam hyper-parameters (as in the reference)")
+        eng.lr, eng.beta1, eng.beta2, eng.adam_eps = go.learning_rate, go.beta_1, go.beta_2, go.epsilon
+        g.bind(eng, eng.G)
+        d.bind(eng, eng.D)
+        go._store, do._store = eng.G, eng.D
+        return eng
 
     # -- losses as standalone evaluations (pix2pix_model.py:44-56); train_step computes them fused ----------------
     def generator_loss(self, fake_predicted, fake_image, real_image):
         fp = torch.as_tensor(fake_predicted, dtype=torch.float32)
-        adv = torch.nn.functional.binary_cross_entropy_with_logits(fp, torch.ones_like(fp))
-        l1 = (torch.as_tensor(real_image, dtype=torch.float32).to(fp.device) - torch.as_tensor(fake_image, dtype=torch.float32).to(fp.device)).abs().mean()
-        return adv + self.lambda_l1 * l1, adv, l1
+        adversarial_loss = self.loss_object(torch.ones_like(fp), fp)
+        real = torch.as_tensor(real_image, dtype=torch.float32).to(fp.device)
+        fake = torch.as_tensor(fake_image, dtype=torch.float32).to(fp.device)
+        l1_loss = (real - fake).abs().mean()
+        total_loss = adversarial_loss + (self.lambda_l1 * l1_loss)
+        return total_loss, adversarial_loss, l1_loss
 
     def discriminator_loss(self, real_predicted, fake_predicted):
         rp = torch.as_tensor(real_predicted, dtype=torch.float32)
         fp = torch.as_tensor(fake_predicted, dtype=torch.float32)
-        real = torch.nn.functional.binary_cross_entropy_with_logits(rp, torch.ones_like(rp))
-        fake = torch.nn.functional.binary_cross_entropy_with_logits(fp, torch.zeros_like(fp))
-        return fake + real, real, fake
+        real_loss = self.loss_object(torch.ones_like(rp), rp)
+        fake_loss = self.loss_object(torch.zeros_like(fp), fp)
+        total_loss = fake_loss + real_loss
+        return total_loss, real_loss, fake_loss
 
     def generate(self, batch):
         """pix2pix_model.py:58-60"""
@@ -68,16 +144,39 @@ class Pix2PixModel(S2SModel):
         return self.generator(source_image, training=True)
 
     # -- the hot path ----------------------------------------------------------------------------------------------
-    def _dp(self):
+    def _check_hooks(self):
+        """The fused step evaluates the loss hooks of the four reference classes only."""
+        if self._hooks_checked:
+            return
+        known = (Pix2PixModel, Pix2PixHistogramModel, Pix2PixIndexedModel)
+        for hook in ("generator_loss", "discriminator_loss"):
+            owner = next((c for c in type(self).__mro__ if hook in c.__dict__), None)
+            if owner not in known:
+                raise NotImplementedError(
+                    f"{type(self).__name__}.{hook} overrides the reference's loss, but train_step here is one fused sequence of "
+                    f"HIP kernels that evaluates the losses of Pix2PixModel / Pix2PixHistogramModel / Pix2PixIndexedModel together "
+                    f"with their gradients (no autograd tape): the override would be ignored.  Add the loss to the engine "
+                    f"(engine.train_step_*) or subclass train_step.")
+        self._hooks_checked = True
+
+    def _shard(self, tensors):
+        """(local shard of every tensor, global batch, samples in front of the shard, DataParallel or None)"""
         dp = self.data_parallel
-        return (1, None) if dp is None else (dp.world, dp)
+        Bg = len(tensors[0])
+        if dp is None:
+            return tensors, Bg, 0, None
+        lo, hi = shard_bounds(Bg, dp.world, dp.rank)
+        return [t[lo:hi] for t in tensors], Bg, lo, dp
 
     def train_step(self, batch, step, update_steps):
         """pix2pix_model.py:62-89"""
+        self._check_hooks()
         source_image, real_image = batch
-        world, dp = self._dp()
-        out = self.engine.train_step_rgba(source_image, real_image, self.lambda_l1,
-                                          global_batch=len(source_image) * world, dp=dp)
+        (src, real), Bg, lo, dp = self._shard([source_image, real_image])
+        if len(src) == 0:
+            out = self.engine.train_step_empty(self.lambda_l1, dp=dp)
+        else:
+            out = self.engine.train_step_rgba(src, real, self.lambda_l1, global_batch=Bg, dp=dp, batch_offset=lo)
         g_loss, d_loss = (out[0], out[1], out[2]), (out[4], out[5], out[6])
         self._log(g_loss, d_loss, step, update_steps)
         return g_loss, d_loss
@@ -120,7 +219,7 @@ class Pix2PixModel(S2SModel):
     def evaluate_l1_batch(self, batch):
         source, target = batch[0], batch[1]
         fake = self.generate((source, target))
-        return float((torch.as_tensor(target, dtype=torch.float32).to(fake.device) - fake).abs().mean())
+        return (torch.as_tensor(target, dtype=torch.float32).to(fake.device) - fake).abs().mean()
 
 
 class Pix2PixAugmentedModel(Pix2PixModel):
@@ -145,11 +244,18 @@ class Pix2PixHistogramModel(Pix2PixAugmentedModel):
         total_loss = total_loss + self.lambda_histogram * histogram_loss
         return total_loss, adversarial_loss, l1_loss, histogram_loss
 
+    def discriminator_loss(self, real_predicted, fake_predicted):
+        return super().discriminator_loss(real_predicted, fake_predicted)
+
     def train_step(self, batch, step, update_steps):
+        self._check_hooks()
         source_image, real_image = batch
-        world, dp = self._dp()
-        out = self.engine.train_step_rgba(source_image, real_image, self.lambda_l1, lambda_hist=self.lambda_histogram,
-                                          global_batch=len(source_image) * world, dp=dp)
+        (src, real), Bg, lo, dp = self._shard([source_image, real_image])
+        if len(src) == 0:
+            out = self.engine.train_step_empty(self.lambda_l1, lambda_hist=self.lambda_histogram, dp=dp)
+        else:
+            out = self.engine.train_step_rgba(src, real, self.lambda_l1, lambda_hist=self.lambda_histogram,
+                                              global_batch=Bg, dp=dp, batch_offset=lo)
         g_loss, d_loss = (out[0], out[1], out[2], out[3]), (out[4], out[5], out[6])
         self._log(g_loss, d_loss, step, update_steps)
         return g_loss, d_loss
@@ -164,12 +270,25 @@ class Pix2PixIndexedModel(Pix2PixModel):
     """pix2pix_model.py:261-330"""
 
     def __init__(self, train_ds, test_ds, model_name, architecture_name, lambda_segmentation=0.5, **kw):
-        super().__init__(train_ds, test_ds, model_name, architecture_name, 0.0, **kw)      # lambda_l1 = 0 (:263)
+        super().__init__(train_ds, test_ds, model_name, architecture_name, 0., **kw)      # lambda_l1 = 0 (:263)
         self.lambda_segmentation = lambda_segmentation
+        self.segmentation_loss_object = CategoricalCrossentropy()
 
-    def create_engine(self):
-        # UnetGenerator(1, MAX_PALETTE_SIZE, "softmax") / PatchDiscriminator(1)  (pix2pix_model.py:267-271)
-        return Pix2PixEngine(1, MAX_PALETTE_SIZE, "softmax", self._img_size, self._dtype, device=self._device, seed=self._seed)
+    def create_generator(self):
+        return UnetGenerator(1, MAX_PALETTE_SIZE, "softmax")
+
+    def create_discriminator(self):
+        return PatchDiscriminator(1)
+
+    def generator_loss(self, fake_predicted, fake_image, real_image):
+        """pix2pix_model.py:273-278 (fake_image = probabilities, real_image = one-hot)"""
+        segmentation_loss = self.segmentation_loss_object(real_image, fake_image)
+        total_loss, adversarial_loss, l1_loss = super().generator_loss(fake_predicted, fake_image, real_image)
+        total_loss = total_loss + self.lambda_segmentation * segmentation_loss
+        return total_loss, adversarial_loss, l1_loss, segmentation_loss
+
+    def discriminator_loss(self, real_predicted, fake_predicted):
+        return super().discriminator_loss(real_predicted, fake_predicted)
 
     def generate(self, batch):
         """pix2pix_model.py:283-287"""
@@ -183,10 +302,13 @@ class Pix2PixIndexedModel(Pix2PixModel):
 
     def train_step(self, batch, step, update_steps):
         """pix2pix_model.py:295-325"""
+        self._check_hooks()
         source_image, real_image, _ = batch
-        world, dp = self._dp()
-        out = self.engine.train_step_indexed(source_image, real_image, self.lambda_segmentation,
-                                             global_batch=len(source_image) * world, dp=dp)
+        (src, real), Bg, lo, dp = self._shard([source_image, real_image])
+        if len(src) == 0:
+            out = self.engine.train_step_empty(0.0, lambda_aux=self.lambda_segmentation, dp=dp)
+        else:
+            out = self.engine.train_step_indexed(src, real, self.lambda_segmentation, global_batch=Bg, dp=dp, batch_offset=lo)
         g_loss, d_loss = (out[0], out[1], out[2], out[3]), (out[4], out[5], out[6])
         self._log(g_loss, d_loss, step, update_steps)
         return g_loss, d_loss
@@ -199,4 +321,4 @@ class Pix2PixIndexedModel(Pix2PixModel):
     def evaluate_l1_batch(self, batch):
         fake = self.generate(batch).to(torch.float32)
         target = torch.as_tensor(batch[1], dtype=torch.float32).to(fake.device)
-        return float((target - fake).abs().mean())
+        return (target - fake).abs().mean()

@@ -1,10 +1,11 @@
 """S2SModel: the training loop the hot path sits behind (reference side2side_model.py:28-126).
 
 Kept: constructor signature, fit/do_fit call order (examples -> loop over train_ds.repeat().take(steps).enumerate()
--> periodic evaluation -> train_step(batch, step, update_steps) -> checkpoint cadence), the overridable hooks and the
-attribute names subclasses use.  Replaced: TensorBoard writer -> a JSON-lines scalar log; tf.train.CheckpointManager
--> a flat-tensor checkpoint (out of scope beyond `.save()`); the matplotlib previews and the
-FID callback (needs an InceptionV3 download, frechet_inception_distance.py:76) are reported as skipped.
+-> periodic evaluation -> train_step(batch, step, update_steps) -> checkpoint cadence), the overridable hooks, the
+attribute names subclasses use, report_l1 over TEST_SIZE images (side2side_model.py:162-176).  Replaced: the TensorFlow
+summary writer -> ScalarLog (JSON lines + a real TensorBoard event file, scalars kept on the device until flush());
+tf.train.Checkpoint / CheckpointManager -> flat-tensor files with the same object structure; the matplotlib previews
+and the FID callback (needs an InceptionV3 download, frechet_inception_distance.py:76) are reported as skipped.
 """
 from abc import ABC, abstractmethod
 import datetime
@@ -12,9 +13,11 @@ import json
 import os
 import time
 
+import numpy as np
 import torch
 
-from .configuration import TEMP_FOLDER
+from . import tb_events
+from .configuration import TEMP_FOLDER, TEST_SIZE
 
 
 def seconds_to_human_readable(seconds):
@@ -36,55 +39,61 @@ def show_eta(training_start_time, step_start_time, current_step, training_starti
 
 
 class ScalarLog:
-    """Stand-in for tf.summary's file writer: scalars appended as JSON lines under the reference's log folder."""
+    """Stand-in for tf.summary's file writer.  scalar() only RECORDS: a device scalar stays on the device (no host
+    synchronisation inside train_step, so the host keeps running ahead of the GPU); flush() -- called by fit() at the end and
+    automatically every `max_pending` rows -- moves all pending values to the host in ONE transfer and appends them to
+    scalars.jsonl and to a TensorBoard event file in the reference's log folder."""
 
-    def __init__(self, folder):
+    def __init__(self, folder, max_pending=4096):
         os.makedirs(folder, exist_ok=True)
         self.path = os.path.join(folder, "scalars.jsonl")
-        self._rows = []
+        self.events = tb_events.EventFileWriter(folder)
+        self.max_pending = max_pending
+        self._rows = []          # (name, value or device tensor, step, wall time)
 
     def scalar(self, name, value, step):
-        self._rows.append({"name": name, "value": float(value), "step": int(step)})
+        self._rows.append((name, value, int(step), time.time()))
+        if len(self._rows) >= self.max_pending:
+            self.flush()
 
     def flush(self):
-        if self._rows:
-            with open(self.path, "a") as f:
-                for r in self._rows:
-                    f.write(json.dumps(r) + "\n")
-            self._rows = []
+        if not self._rows:
+            return
+        rows, self._rows = self._rows, []
+        dev = [i for i, r in enumerate(rows) if isinstance(r[1], torch.Tensor) and r[1].is_cuda]
+        host = {}
+        if dev:
+            stacked = torch.stack([rows[i][1].detach().reshape(()).to(torch.float32) for i in dev]).cpu().numpy()
+            host = {i: float(v) for i, v in zip(dev, stacked)}
+        out = [(r[0], host[i] if i in host else float(r[1]), r[2], r[3]) for i, r in enumerate(rows)]
+        with open(self.path, "a") as f:
+            for name, value, step, _ in out:
+                f.write(json.dumps({"name": name, "value": value, "step": step}) + "\n")
+        self.events.add_scalars(out)
 
 
-class CheckpointManager:
-    """`.save()` as do_fit calls it (side2side_model.py:121-122): generator, discriminator and both Adam states."""
+class Checkpoint:
+    """tf.train.Checkpoint(generator_optimizer=, discriminator_optimizer=, generator=, discriminator=)
+    (pix2pix_model.py:30-34): the objects whose state a checkpoint holds.  All of that state lives in the engine's flat
+    buffers: weights, Adam moments and step counts of both networks, and the device dropout counter."""
 
-    def __init__(self, engine, directory, max_to_keep=1):
-        self.engine, self.directory, self.max_to_keep = engine, directory, max_to_keep
-        self.saved = []
+    def __init__(self, generator_optimizer=None, discriminator_optimizer=None, generator=None, discriminator=None, engine=None):
+        self.generator_optimizer, self.discriminator_optimizer = generator_optimizer, discriminator_optimizer
+        self.generator, self.discriminator, self.engine = generator, discriminator, engine
 
-    def save(self):
-        os.makedirs(self.directory, exist_ok=True)
-        path = os.path.join(self.directory, f"ckpt-{len(self.saved) + 1}.pt")
+    def state(self):
         e = self.engine
-        torch.save({"G": e.G.params.cpu(), "G.m": e.G.m.cpu(), "G.v": e.G.v.cpu(), "G.t": e.G.t,
-                    "D": e.D.params.cpu(), "D.m": e.D.m.cpu(), "D.v": e.D.v.cpu(), "D.t": e.D.t,
-                    "mask_counter": int(e.mask_counter_dev.item()), "step_count": e.step_count}, path)
-        self.saved.append(path)
-        while len(self.saved) > self.max_to_keep:
-            old = self.saved.pop(0)
-            if os.path.exists(old):
-                os.remove(old)
+        return {"G": e.G.params.cpu(), "G.m": e.G.m.cpu(), "G.v": e.G.v.cpu(), "G.t": e.G.t,
+                "D": e.D.params.cpu(), "D.m": e.D.m.cpu(), "D.v": e.D.v.cpu(), "D.t": e.D.t,
+                "mask_counter": int(e.mask_counter_dev.item()), "step_count": e.step_count}
+
+    def save(self, path):
+        torch.save(self.state(), path)
         return path
 
-    @property
-    def latest_checkpoint(self):
-        return self.saved[-1] if self.saved else None
-
-    def restore(self, path=None):
-        """Resume: weights, both Adam states (moments and step counts) and the dropout counter, so that the next step
-        is the one that would have followed the save (tf.train.Checkpoint.restore in the reference's workflow)."""
-        path = path or self.latest_checkpoint
-        if path is None:
-            raise FileNotFoundError("no checkpoint to restore")
+    def restore(self, path):
+        """weights, both Adam states (moments and step counts) and the dropout counter, so that the next step is the one that
+        would have followed the save"""
         ck = torch.load(path, map_location="cpu")
         e = self.engine
         for store, k in ((e.G, "G"), (e.D, "D")):
@@ -97,6 +106,35 @@ class CheckpointManager:
         e.step_count = int(ck.get("step_count", 0))
         e.refresh_weight_copies()
         return path
+
+
+class CheckpointManager:
+    """tf.train.CheckpointManager(checkpoint, directory=, max_to_keep=1) (pix2pix_model.py:35-36); `.save()` as do_fit
+    calls it (side2side_model.py:121-122)."""
+
+    def __init__(self, checkpoint, directory, max_to_keep=1):
+        self.checkpoint, self.directory, self.max_to_keep = checkpoint, directory, max_to_keep
+        self.saved = []
+
+    def save(self):
+        os.makedirs(self.directory, exist_ok=True)
+        path = self.checkpoint.save(os.path.join(self.directory, f"ckpt-{len(self.saved) + 1}.pt"))
+        self.saved.append(path)
+        while len(self.saved) > self.max_to_keep:
+            old = self.saved.pop(0)
+            if os.path.exists(old):
+                os.remove(old)
+        return path
+
+    @property
+    def latest_checkpoint(self):
+        return self.saved[-1] if self.saved else None
+
+    def restore(self, path=None):
+        path = path or self.latest_checkpoint
+        if path is None:
+            raise FileNotFoundError("no checkpoint to restore")
+        return self.checkpoint.restore(path)
 
 
 class S2SModel(ABC):
@@ -140,7 +178,7 @@ class S2SModel(ABC):
                     print("Discriminator output patches: plotting is not part of this build (skipped)")
                 if "evaluate_l1" in callbacks:
                     l1_train, l1_test = self.report_l1(step=(step + 1) // update_steps)
-                    print(f" L1: {l1_train:.5f} / {l1_test:.5f} (train/test)")
+                    print(f" L1: {float(l1_train):.5f} / {float(l1_test):.5f} (train/test)")
                 if "evaluate_fid" in callbacks:
                     print("FID needs the InceptionV3 ImageNet weights (network fetch): skipped")
                 print(f"Step: {(step + 1) / 1000}k")
@@ -160,17 +198,60 @@ class S2SModel(ABC):
     def preview_generated_images_during_training(self, examples, save_name, step):
         pass
 
-    def report_l1(self, step=None, num_batches=8):
-        """side2side_model.py:162-176: mean |target - generated| over a few batches of train and test."""
-        out = []
-        for ds in (self.train_ds, self.test_ds):
-            tot, cnt = 0.0, 0
-            for batch in ds.take(num_batches):
-                l1 = self.evaluate_l1_batch(batch)
-                tot += l1 * len(batch[0])
-                cnt += len(batch[0])
-            out.append(tot / max(cnt, 1))
+    # -- evaluation (side2side_model.py:140-176) ---------------------------------------------------------------------------
+    def select_examples_for_evaluation(self, num_images, dataset):
+        """pix2pix_model.py:112-122 / :433-452: (real_images, fake_images) of the first num_images samples, each generated as a
+        batch of one like the reference does; indexed batches are looked up in their palette (io_utils.py:96-103)."""
+        from . import io_utils
+        real, fake = [], []
+        for batch in dataset.unbatch().take(num_images).batch(1):
+            out = self.generate(batch)
+            if len(batch) == 3:          # (source_idx, target_idx, palette)
+                pal = torch.as_tensor(np.asarray(batch[2][0]))
+                real.append(io_utils.indexed_to_rgba(torch.as_tensor(np.asarray(batch[1][0])), pal).to(torch.float32))
+                fake.append(io_utils.indexed_to_rgba(out[0].cpu(), pal).to(torch.float32))
+            else:
+                real.append(torch.as_tensor(np.asarray(batch[1][0]), dtype=torch.float32))
+                fake.append(out[0].to(torch.float32).cpu())
+        return torch.stack(real), torch.stack(fake)
+
+    def evaluate_l1(self, real_images, fake_images):
+        """pix2pix_model.py:124-125"""
+        return (torch.as_tensor(fake_images, dtype=torch.float32) - torch.as_tensor(real_images, dtype=torch.float32)).abs().mean()
+
+    # -- model export (side2side_model.py:178-200: the reference writes SavedModels; here the documented Keras-layout file) --
+    def _model_path(self, which):
+        return os.sep.join(["models", "py", which, self.architecture_name, self.model_name])
+
+    def save_generator(self):
+        """side2side_model.py:178-184: `models/py/generator/<architecture>/<model>/weights.p2pw.npz` (keras_weights.py)"""
+        from . import keras_weights
+        os.makedirs(self._model_path("generator"), exist_ok=True)
+        return keras_weights.export_model(self, os.path.join(self._model_path("generator"), "weights.p2pw.npz"))
+
+    def save_discriminator(self):
+        """side2side_model.py:190-196"""
+        from . import keras_weights
+        os.makedirs(self._model_path("discriminator"), exist_ok=True)
+        return keras_weights.export_model(self, os.path.join(self._model_path("discriminator"), "weights.p2pw.npz"))
+
+    def load_generator(self):
+        """side2side_model.py:186-188"""
+        from . import keras_weights
+        keras_weights.import_model(self, os.path.join(self._model_path("generator"), "weights.p2pw.npz"))
+
+    def load_discriminator(self):
+        """side2side_model.py:198-200"""
+        from . import keras_weights
+        keras_weights.import_model(self, os.path.join(self._model_path("discriminator"), "weights.p2pw.npz"))
+
+    def report_l1(self, num_images=TEST_SIZE, step=None):
+        """side2side_model.py:162-176"""
+        train_real_images, train_fake_images = self.select_examples_for_evaluation(num_images, self.train_ds)
+        test_real_images, test_fake_images = self.select_examples_for_evaluation(num_images, self.test_ds)
+        train_value = self.evaluate_l1(train_real_images, train_fake_images)
+        test_value = self.evaluate_l1(test_real_images, test_fake_images)
         if self.summary_writer is not None and step is not None:
-            self.summary_writer.scalar("l1_evaluation/train", out[0], step)
-            self.summary_writer.scalar("l1_evaluation/test", out[1], step)
-        return tuple(out)
+            self.summary_writer.scalar("l1-evaluation/train", train_value, step)
+            self.summary_writer.scalar("l1-evaluation/test", test_value, step)
+        return train_value, test_value

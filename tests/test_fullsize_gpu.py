@@ -1,0 +1,114 @@
+"""-m gpu: the BASELINE.json batch sizes under test (not only under bench.py).  Size-independent property: every sample of
+a train step is independent of the others (InstanceNorm, dropout, both networks are per-sample), so a
+step at the full per-GPU batch must give, image by image, what the same images give in sub-batches of 8 evaluated with
+the GLOBAL loss denominators -- and its gradient must be the sum of the sub-batch gradients.  The full batch takes the
+launch paths that only large batches reach (split-K = 1 with fused statistics, 256-row tiles, the block-resident kernel with
+256 workgroups, persistent few-input / few-output workgroups, multi-strip weight gradients, the narrow InstanceNorm
+backward); the sub-batches take the small-batch paths the oracle tests pin.  Dropout masks come from the device RNG: it
+is keyed by the global sample index, so sub-batch k (batch_offset = 8 k) draws exactly the rows of the full batch's mask."""
+import numpy as np
+import pytest
+import torch
+
+from palette_and_histo_gan_amd import _lib as L
+from palette_and_histo_gan_amd import dataset_utils as DU
+from palette_and_histo_gan_amd import engine as E
+from tests import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+SUB = 8
+
+
+def _fake_of(eng, B):
+    P = eng.plans[B]
+    return U.halo_to_np(P["dcat"])[B:2 * B, ..., :eng.in_ch].copy()
+
+
+def _run(eng, indexed, src, tgt, lam, lam_hist, Bg, off):
+    if indexed:
+        out = eng.train_step_indexed(src, tgt, lam, global_batch=Bg, apply_update=False, batch_offset=off)
+    else:
+        out = eng.train_step_rgba(src, tgt, lam, lambda_hist=lam_hist, global_batch=Bg, apply_update=False, batch_offset=off)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name,model,B,S,dtype,lam,nsub", [
+    ("c2", "baseline", 256, 64, L.F32, 100.0, 32), ("c2", "baseline", 256, 64, L.BF16, 100.0, 32),
+    ("c4", "indexed", 128, 64, L.BF16, 0.01, 16), ("c5", "baseline", 256, 128, L.BF16, 30.0, 4)])
+def test_full_batch_equals_its_sub_batches(name, model, B, S, dtype, lam, nsub):
+    """c2 (B = 256, both dtypes), c4 (indexed head, B = 128 per GPU), c5's shape (128x128 sprites, B = 256; its first 32
+    images are re-run in sub-batches).  Checked per image: the generated image; over the batch: the additive loss sums and,
+    where all sub-batches are run, every gradient tensor."""
+    indexed = model == "indexed"
+    rng = np.random.default_rng(61)
+    if indexed:
+        eng = E.Pix2PixEngine(1, 256, "softmax", S, dtype, device=U.DEV)
+        src, tgt, _ = DU.synthetic_indexed_batch(rng, B, S, 24)
+    else:
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype, device=U.DEV)
+        src, tgt = DU.synthetic_rgba_batch(rng, B, S, palette_size=24)
+    # move gamma/beta off their (1, 0) initial values so that every normalisation parameter matters
+    g = eng.G.export()
+    for k in g:
+        if k.endswith(".gamma"):
+            g[k] = (1 + 0.2 * rng.normal(size=g[k].shape)).astype(np.float32)
+        elif k.endswith(".beta"):
+            g[k] = (0.2 * rng.normal(size=g[k].shape)).astype(np.float32)
+    eng.set_params(g, None)
+    full = _run(eng, indexed, src, tgt, lam, None, B, 0)
+    fake_full = _fake_of(eng, B)
+    g_full = eng.G.grads.cpu().numpy().astype(np.float64)
+    d_full = eng.D.grads.cpu().numpy().astype(np.float64)
+    sums = np.zeros(7)
+    g_sum, d_sum = np.zeros_like(g_full), np.zeros_like(d_full)
+    f32 = dtype == L.F32
+    for k in range(nsub):
+        sl = slice(k * SUB, (k + 1) * SUB)
+        sums += _run(eng, indexed, src[sl], tgt[sl], lam, None, B, k * SUB)
+        fk = _fake_of(eng, SUB)
+        ref = fake_full[sl]
+        if indexed:       # palette indices: identical wherever the two launch paths do not sit on a near-tie of the softmax
+            assert (fk == ref).mean() > 0.98
+        elif f32:
+            assert np.abs(fk - ref).max() <= 2e-5          # f32 through 13 layers with different summation orders
+        else:             # bf16 storage: the two launch paths round different partial sums, a few units in the last place
+            assert np.abs(fk - ref).max() <= 6e-2 and np.abs(fk - ref).mean() <= 3e-3
+        g_sum += eng.G.grads.cpu().numpy()
+        d_sum += eng.D.grads.cpu().numpy()
+    if nsub * SUB == B:
+        tol = 2e-5 if f32 else 5e-3
+        for i in (1, 2, 3, 5, 6):        # the additive loss terms (totals are affine in them)
+            assert abs(sums[i] - full[i]) <= tol * max(abs(full[i]), 1e-6), (i, sums[i], full[i])
+        for store, a, b in ((eng.G, g_sum, g_full), (eng.D, d_sum, d_full)):
+            for key in store.shapes:
+                o, n = store.offsets[key], int(np.prod(store.shapes[key]))
+                x, y = a[o:o + n], b[o:o + n]
+                err = np.linalg.norm(x - y) / (np.linalg.norm(y) + 1e-30)
+                # f32: summation order only (a ReLU input within rounding of zero may flip); bf16: the storage noise of two
+                # different launch paths
+                assert err <= (5e-3 if f32 else 0.25), (key, err)
+
+
+@pytest.mark.timeout(900)
+def test_histogram_model_full_batch_c3():
+    """c3 (histogram model, B = 256, palette 24): the RGB-uv histograms of the full batch equal the per-image histograms
+    taken in sub-batches (f32 path in both dtypes), and the fused Hellinger loss equals the loss recomputed from them."""
+    B, S = 256, 64
+    rng = np.random.default_rng(62)
+    src, tgt = DU.synthetic_rgba_batch(rng, B, S, palette_size=24)
+    for dtype in (L.F32, L.BF16):
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype, device=U.DEV)
+        out = eng.train_step_rgba(src, tgt, 30.0, lambda_hist=1.0, apply_update=False).cpu().numpy()
+        fake = _fake_of(eng, B)
+        h_real = eng.rgbuv_histogram(tgt).cpu().numpy().astype(np.float64)
+        h_fake = eng.rgbuv_histogram(fake).cpu().numpy().astype(np.float64)
+        for k in (0, 9, 31):
+            sl = slice(k * SUB, (k + 1) * SUB)
+            hk = eng.rgbuv_histogram(tgt[sl]).cpu().numpy()
+            assert np.abs(hk - h_real[sl]).max() <= 1e-6
+        hell = np.sqrt(((np.sqrt(h_fake) - np.sqrt(h_real)) ** 2).sum()) / np.sqrt(2.0) / B
+        # the fused loss sees the f32 image that tanh produced; `fake` above went through the activation dtype
+        assert abs(out[3] - hell) <= (1e-4 if dtype == L.F32 else 2e-2) * hell, (dtype, out[3], hell)
+        assert np.isfinite(eng.G.grads.cpu().numpy()).all()

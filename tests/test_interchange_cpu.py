@@ -1,0 +1,99 @@
+"""Not-gpu: host-side pieces around the hot path -- the Keras-layout weight file, the palette helpers of
+io_utils.py (bit-exact integer work, F1/F3) and the TensorBoard event writer (F4)."""
+import numpy as np
+import pytest
+import torch
+
+from palette_and_histo_gan_amd import engine as E
+from palette_and_histo_gan_amd import io_utils
+from palette_and_histo_gan_amd import keras_weights as KW
+from palette_and_histo_gan_amd import tb_events
+from palette_and_histo_gan_amd.configuration import INVALID_INDEX_COLOR, MAX_PALETTE_SIZE
+
+
+class _HostEngine:
+    """the two parameter stores of an engine, on the CPU (keras_weights only touches G, D and refresh_weight_copies)"""
+
+    def __init__(self, in_ch=4, out_ch=4, seed=0):
+        self.G = E.ParamStore(E.generator_param_shapes(in_ch, out_ch), "cpu")
+        self.D = E.ParamStore(E.discriminator_param_shapes(in_ch), "cpu")
+        rng = np.random.default_rng(seed)
+        for st in (self.G, self.D):
+            st.params.copy_(torch.as_tensor(rng.normal(size=st.numel).astype(np.float32)))
+            st.m.copy_(torch.as_tensor(rng.normal(size=st.numel).astype(np.float32)))
+            st.v.copy_(torch.as_tensor(rng.random(size=st.numel).astype(np.float32)))
+            st.t = int(rng.integers(1, 1000))
+        self.refreshed = 0
+
+    def refresh_weight_copies(self):
+        self.refreshed += 1
+
+
+def test_keras_layout_weight_file_round_trip(tmp_path):
+    a, b = _HostEngine(seed=1), _HostEngine(seed=2)
+    path = KW.export_model(a, str(tmp_path / "front2right.p2pw.npz"))
+    z = np.load(path)
+    # Keras variable order and layouts (networks.py:39-98): 36 generator arrays, 3 discriminator arrays
+    gen = sorted(k for k in z.files if k.startswith("generator/"))
+    assert len(gen) == 36 and gen[0] == "generator/000:down1.kernel" and gen[-1] == "generator/035:last.bias"
+    assert z["generator/000:down1.kernel"].shape == (4, 4, 4, 64)            # Conv2D: HWIO
+    assert z["generator/016:up1.kernel"].shape == (4, 4, 512, 512)           # Conv2DTranspose: (kh, kw, Cout, Cin)
+    assert z["generator/031:up6.kernel"].shape == (4, 4, 32, 128)
+    assert z["generator/034:last.kernel"].shape == (4, 4, 36, 4)
+    assert sorted(k for k in z.files if k.startswith("discriminator/")) == [
+        "discriminator/000:down.kernel", "discriminator/001:last.kernel", "discriminator/002:last.bias"]
+    assert sum(int(np.prod(z[k].shape)) for k in gen) == 29_307_844
+    KW.import_model(b, path)
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        for k in sa.shapes:         # per-variable: the flat buffers also hold alignment padding
+            for buf in ("params", "m", "v"):
+                assert torch.equal(sa.view(getattr(sa, buf), k), sb.view(getattr(sb, buf), k)), (k, buf)
+        assert sa.t == sb.t and int(sb.t_dev[0]) == sb.t
+    assert b.refreshed == 1
+    # the reference side reads the same file as a plain list for keras.Model.set_weights
+    lst = KW.load_weight_list(path, "generator")
+    assert len(lst) == 36 and np.array_equal(lst[1], a.G.export()["down2.kernel"])
+    # a file whose variables are out of order is refused
+    bad = {k: z[k] for k in z.files}
+    bad["generator/001:down2.gamma"] = bad.pop("generator/001:down2.kernel")
+    np.savez(str(tmp_path / "bad.npz"), **bad)
+    with pytest.raises(ValueError):
+        KW.import_model(b, str(tmp_path / "bad.npz"))
+
+
+def test_palette_extraction_and_index_round_trip_are_bit_exact():
+    rng = np.random.default_rng(7)
+    colours = np.array([[0, 0, 0, 0], [10, 20, 30, 255], [200, 10, 10, 255], [10, 200, 10, 255], [250, 250, 250, 255],
+                        [30, 30, 30, 255], [31, 29, 30, 255]], np.int32)
+    img = colours[rng.integers(0, len(colours), size=(64, 64))]
+    img[0, 0] = colours[4]                          # first appearance order: the brightest colour comes first
+    pal = io_utils.extract_palette(img, "grayness")
+    assert pal.shape == (MAX_PALETTE_SIZE, 4) and pal.dtype == np.int32
+    n = len(colours)
+    gray = (colours[:, :3].astype(np.float32) * np.array([0.2989, 0.5870, 0.1140], np.float32)).sum(1)
+    assert np.array_equal(pal[:n], colours[np.argsort(gray, kind="stable")])        # dark to light (io_utils.py:45-50)
+    assert np.array_equal(pal[0], [0, 0, 0, 0])                                       # transparent black is index 0
+    assert (pal[n:] == np.array(INVALID_INDEX_COLOR)).all()                           # padded with the invalid colour
+    top = io_utils.extract_palette(img, "top2bottom")
+    assert np.array_equal(top[0], colours[4])                                         # UniqueWithCounts: order of first appearance
+    idx = io_utils.rgba_to_indexed(img, pal)
+    assert idx.shape == (64, 64, 1) and idx.dtype == np.int32 and idx.max() < n
+    back = io_utils.indexed_to_rgba(idx, pal)
+    assert np.array_equal(back, img)
+    back_t = io_utils.indexed_to_rgba(torch.as_tensor(idx), torch.as_tensor(pal))
+    assert np.array_equal(back_t.numpy(), img)
+    # equal grayness: the stable sort keeps the order of first appearance
+    tie = np.array([[[100, 0, 0, 255], [0, 0, 0, 255]], [[100, 0, 0, 255], [100, 0, 0, 255]]], np.int32)
+    assert np.array_equal(io_utils.extract_palette(tie, "grayness")[:2], [[0, 0, 0, 255], [100, 0, 0, 255]])
+    with pytest.raises(ValueError):
+        io_utils.extract_palette(rng.integers(0, 256, size=(64, 64, 4)), "grayness")    # > 256 colours
+
+
+def test_tensorboard_event_file_round_trip(tmp_path):
+    assert tb_events.crc32c(b"123456789") == 0xE3069283                               # CRC-32C check value
+    w = tb_events.EventFileWriter(str(tmp_path))
+    rows = [("generator/total_loss", 34.5, 0, 1.0), ("generator/l1_loss", 0.25, 0, 1.5), ("discriminator/real_loss", 1e-7, 40, 2.0)]
+    w.add_scalars(rows)
+    got = list(tb_events.read_events(w.path))
+    assert [(t, s) for s, t, _ in got] == [(r[0], r[2]) for r in rows]
+    np.testing.assert_allclose([v for _, _, v in got], [r[1] for r in rows], rtol=1e-6)

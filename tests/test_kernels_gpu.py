@@ -255,8 +255,10 @@ def test_losses(dtype):
     fb, dzb = E.HaloBuf(n, s, s, c, dtype, U.DEV), E.HaloBuf(n, s, s, c, dtype, U.DEV)
     inv = 1.0 / (n * s * s * c)
     l1_row = part[3 * 256:]
+    f32copy = torch.empty((n, s, s, c), dtype=torch.float32, device=U.DEV)
     L.call("p2p_tanh_l1_fwd", dtype, n, s, s, c, C.byref(zb.view()), C.byref(rb.view()), C.byref(fb.view()), inv,
-           U.ptr(l1_row), U.stream())
+           U.ptr(l1_row), U.ptr(f32copy), U.stream())
+    assert np.abs(f32copy.cpu().numpy() - np.tanh(z.astype(np.float64))).max() < 1e-6       # unrounded copy for the histogram loss
     L.call("p2p_loss_partials_sum", U.ptr(part), 4, U.ptr(loss), U.stream())
     zt = torch.tensor(z, dtype=F64, requires_grad=True)
     fake_t = torch.tanh(zt)
@@ -287,6 +289,44 @@ def test_adam_matches_keras_formulation():
         pr, mr, vr = npr.keras_adam_step(pr, g.astype(np.float64), mr, vr, t)
     np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(vd.cpu().numpy(), vr, rtol=5e-5)   # (1 - 0.999f) in f32, as keras does
+
+
+def test_adam_device_step_state_matches_keras_formulation():
+    """The variant the engine runs: p2p_adam_tick advances t and the step size in device memory, p2p_adam_flat_dev reads it
+    (tf.keras.optimizers.Adam(2e-4, beta_1=0.5), pix2pix_model.py:28-29,81-83)."""
+    rng = np.random.default_rng(14)
+    n = 5003
+    p0 = rng.normal(size=n).astype(np.float32)
+    pd, md, vd = U.dev(p0), torch.zeros(n, device=U.DEV), torch.zeros(n, device=U.DEV)
+    t_dev = torch.zeros(1, dtype=torch.int32, device=U.DEV)
+    lr_dev = torch.zeros(1, dtype=torch.float32, device=U.DEV)
+    pr, mr, vr = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in range(1, 5):
+        g = (rng.normal(size=n) * 10.0 ** rng.integers(-6, 1, size=n)).astype(np.float32)
+        gd = U.dev(g)
+        L.call("p2p_adam_tick", U.ptr(t_dev), U.ptr(lr_dev), 2e-4, 0.5, 0.999, U.stream())
+        L.call("p2p_adam_flat_dev", U.ptr(pd), U.ptr(gd), U.ptr(md), U.ptr(vd), n, U.ptr(lr_dev), 0.5, 0.999, 1e-7, 1.0, U.stream())
+        pr, mr, vr = npr.keras_adam_step(pr, g.astype(np.float64), mr, vr, t)
+        assert int(t_dev[0]) == t
+        assert abs(float(lr_dev[0]) - 2e-4 * np.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)) < 1e-9
+    np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), vr, rtol=5e-5)
+
+
+def test_dropout_mask_of_a_shard_is_the_slice_of_the_global_mask():
+    """Data parallelism: rank r draws the keep-mask of its samples from the global element index, so N ranks
+    together reproduce the single-process mask of the global batch."""
+    per, Bg = 2 * 2 * 512, 6                     # elements per sample of up1's mask, global batch
+    cnt = torch.tensor([3], dtype=torch.int64, device=U.DEV)
+    whole = torch.empty(Bg * per, dtype=torch.uint8, device=U.DEV)
+    L.call("p2p_dropout_mask_dev", U.ptr(whole), Bg * per, 47, U.ptr(cnt), 1, 0, U.stream())
+    for lo, hi in ((0, 2), (2, 5), (5, 6)):      # ragged shards
+        part = torch.empty((hi - lo) * per, dtype=torch.uint8, device=U.DEV)
+        L.call("p2p_dropout_mask_dev", U.ptr(part), (hi - lo) * per, 47, U.ptr(cnt), 1, lo * per, U.stream())
+        assert torch.equal(part, whole[lo * per:hi * per])
+    other = torch.empty(Bg * per, dtype=torch.uint8, device=U.DEV)
+    L.call("p2p_dropout_mask_dev", U.ptr(other), Bg * per, 47, U.ptr(cnt), 2, 0, U.stream())     # another layer: another stream
+    assert abs(float((other == whole).float().mean()) - 0.5) < 2e-2
 
 
 def test_dropout_mask_is_fair_and_reproducible():
@@ -435,7 +475,9 @@ def test_edge_layers_on_mfma(dtype, n, lh, cg, cd, stride, entry="p2p_igemm_edge
                msplit, U.ptr(ws), U.stream())
         assert U.rel_err(dw.cpu().numpy().reshape(4, 4, cg, cd), w_ref) < 2e-5, msplit
     db = torch.empty(cd, dtype=torch.float32, device=U.DEV)
-    L.call("p2p_view_colsum", dtype, n, lh, lh, cd, C.byref(lo_b.view()), U.ptr(db), U.stream())
+    lv = lo_b.view()
+    cs_ws = torch.empty(max(16, L.lib().p2p_view_colsum_workspace_bytes(dtype, n, lh, lh, cd, C.byref(lv)) // 4), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_view_colsum", dtype, n, lh, lh, cd, C.byref(lv), U.ptr(db), U.ptr(cs_ws), U.stream())
     assert U.rel_err(db.cpu().numpy(), lo.astype(np.float64).sum(axis=(0, 1, 2))) < 2e-5
 
 

@@ -30,7 +30,17 @@ def test_fit_loop_runs_like_the_notebook(tmp_path, monkeypatch):
     assert model.engine.G.t == 7 and not torch.equal(w0, model.generator.trainable_variables[0])
     assert len(model.checkpoint_manager.saved) == 1 and os.path.exists(model.checkpoint_manager.saved[0])
     rows = [r for r in open(model.summary_writer.path)]
-    assert any("generator/l1_loss" in r for r in rows) and any("l1_evaluation/test" in r for r in rows)
+    assert any("generator/l1_loss" in r for r in rows) and any("l1-evaluation/test" in r for r in rows)
+    # the same scalars as a TensorBoard event file (what the reference's tf.summary calls leave behind)
+    from palette_and_histo_gan_amd import tb_events
+    ev = list(tb_events.read_events(model.summary_writer.events.path))
+    assert sum(1 for _, tag, _ in ev if tag == "generator/l1_loss") == 7 and all(np.isfinite(v) for _, _, v in ev)
+    # the reference's attribute surface (pix2pix_model.py:12-36)
+    assert model.loss_object is not None and model.checkpoint.generator is model.generator
+    assert model.generator_optimizer.learning_rate == 0.0002 and model.generator_optimizer.beta_1 == 0.5
+    assert model.generator_optimizer.iterations == 7
+    adv = model.loss_object(torch.ones(3), torch.zeros(3))
+    assert abs(float(adv) - np.log(2.0)) < 1e-6
     g_loss, d_loss = model.train_step(next(iter(train)), 7, 3)
     assert len(g_loss) == 3 and len(d_loss) == 3 and all(torch.isfinite(x) for x in g_loss + d_loss)
     fake = model.generate(next(iter(test)))
@@ -39,13 +49,53 @@ def test_fit_loop_runs_like_the_notebook(tmp_path, monkeypatch):
     assert tuple(logits.shape) == (4, 32, 32, 1)
 
 
-def test_checkpoint_restore_resumes_bit_exactly(tmp_path, monkeypatch):
-    """save -> two more steps -> restore -> the same two steps: weights, Adam moments / step counts and the device
-    dropout counter all come back, so the replayed steps reproduce the first run bit for bit (f32 mode, deterministic
-    kernels: every reduction has a fixed order)."""
+def test_scalar_log_does_not_synchronise_and_hooks_fail_loudly(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     train = D.synthetic_rgba_ds(8, batch_size=4)
-    model = M.Pix2PixModel(train, train, "front2right", "pix2pix-ckpt-test", lambda_l1=100.0, dtype="f32")
+    model = M.Pix2PixModel(train, train, "front2right", "pix2pix-hooks-test", lambda_l1=100.0)
+    model.fit(1, 1)
+    model.train_step(next(iter(train)), 1, 1)
+    pend = model.summary_writer._rows
+    assert len(pend) == 6 and all(isinstance(r[1], torch.Tensor) and r[1].is_cuda for r in pend)      # still on the device
+    model.summary_writer.flush()
+    assert not model.summary_writer._rows
+
+    class Custom(M.Pix2PixModel):          # a subclass that changes the loss cannot be honoured by the fused step
+        def generator_loss(self, fake_predicted, fake_image, real_image):
+            return super().generator_loss(fake_predicted, fake_image, real_image)
+
+    c = Custom(train, train, "front2right", "pix2pix-hooks-test", lambda_l1=100.0)
+    with pytest.raises(NotImplementedError, match="fused"):
+        c.train_step(next(iter(train)), 0, 1)
+
+    class OneChannel(M.Pix2PixIndexedModel):        # the builders take the reference's arguments (networks.py:39,53)
+        def create_generator(self):
+            return M.UnetGenerator(1, 256, "softmax")
+
+    o = OneChannel(D.synthetic_indexed_ds(4, batch_size=4), None, "front2right", "pix2pix-hooks-test")
+    assert o.generator.count_params() == 29_437_888 and o.generator.input_channels == 1
+    # Keras-order weight list round trip through the handle
+    w = o.discriminator.get_weights()
+    o.discriminator.set_weights(list(w.values()))
+    with pytest.raises(ValueError):
+        o.discriminator.set_weights(list(w.values())[:-1])
+
+
+@pytest.mark.parametrize("kind", ["baseline", "histogram", "indexed"])
+def test_checkpoint_restore_resumes_bit_exactly(tmp_path, monkeypatch, kind):
+    """save -> two more steps -> restore -> the same two steps: weights, Adam moments / step counts and the device
+    dropout counter all come back, so the replayed steps reproduce the first run bit for bit (f32 mode; every reduction of
+    the step has a fixed order: no float atomics in the loss, histogram or softmax kernels)."""
+    monkeypatch.chdir(tmp_path)
+    if kind == "indexed":
+        train = D.synthetic_indexed_ds(8, batch_size=4)
+        model = M.Pix2PixIndexedModel(train, train, "front2right", "pix2pix-ckpt-test", lambda_segmentation=0.01, dtype="f32")
+    elif kind == "histogram":
+        train = D.synthetic_rgba_ds(8, batch_size=4, palette_size=24)
+        model = M.Pix2PixHistogramModel(train, train, "front2right", "pix2pix-ckpt-test", 30.0, 1.0, dtype="f32")
+    else:
+        train = D.synthetic_rgba_ds(8, batch_size=4)
+        model = M.Pix2PixModel(train, train, "front2right", "pix2pix-ckpt-test", lambda_l1=100.0, dtype="f32")
     batches = list(iter(train))
     model.fit(2, 1)
     path = model.checkpoint_manager.save()
