@@ -88,7 +88,8 @@ def kernel_profile(eng, run_step, n_steps=3):
         a.record()
         orig(name, *args)
         b.record()
-        records.append((name, args[:8], a, b))
+        # the fused block (convolution + InstanceNorm + activation) is the same kernel family as p2p_igemm, which dispatches to it
+        records.append(("p2p_igemm" if name == "p2p_igemm_norm_act" else name, args[:8], a, b))
 
     L.call = timed
     E.L.call = timed
@@ -216,14 +217,21 @@ def main():
             prof, records = kernel_profile(eng, run_step_local)
             result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
             result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype, MFMA_PEAK[args.dtype])
-            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; reduced
-            # by tools/pmc_traffic.py from separate --pmc runs of this same command and committed under profiles/)
+            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; reduced by
+            # tools/pmc_traffic.py from separate --pmc runs of this same command and committed under profiles/).  The profile is
+            # stamped with a fingerprint of the kernel sources + engine: a profile taken from other code is NOT quoted.
+            from palette_and_histo_gan_amd.build import source_fingerprint
             pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}_{args.dtype}.json")
+            result["roofline"]["traffic"] = None
             if os.path.exists(pmc):
-                k = json.load(open(pmc))["kernels"].get(result["roofline"]["kernel"])
-                if k and k.get("hbm_bytes_per_launch"):
+                prof_json = json.load(open(pmc))
+                k = prof_json["kernels"].get(result["roofline"]["kernel"])
+                if prof_json.get("fingerprint") != source_fingerprint():
+                    result["roofline"]["traffic_note"] = "profiles/ counter file was taken from different sources: not quoted"
+                elif k and k.get("hbm_bytes_per_launch"):
                     result["roofline"]["traffic"] = round(k["hbm_bytes_per_launch"])
                     result["roofline"]["traffic_unit"] = "bytes/launch (PMC)"
+                    result["roofline"]["traffic_launches_profiled"] = k.get("launches_fetch_pass")
             if args.detail:
                 FL.write_detail(records, args.detail, n_steps=3)
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only

@@ -99,6 +99,15 @@ int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols);
  * by itself whenever p2p_brig_ok says the shape qualifies (environment P2P_BRIG=0 keeps the im2col kernel);
  * p2p_igemm_layer_stat_slots is the statistics-slot query that matches the kernel p2p_igemm will use for the layer. */
 int p2p_brig_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+/* The whole block of networks.py:7-21 / 24-36 (without dropout) in ONE launch where a workgroup holds whole images (lo maps up
+ * to 16x16): convolution, InstanceNorm statistics, normalisation and LeakyReLU / ReLU.  Writes the rounded convolution result
+ * to the output view of the op (dense raw tensor: the backward pass reads it), (mean, rstd) to stats[N][Cout][2] and
+ * act(gamma * (x - mean) * rstd + beta) into the (haloed, channel-sliced) view act_out.  p2p_igemm_norm_act_ok tells whether
+ * the shape qualifies; otherwise p2p_igemm + p2p_norm_act_fwd do the same in two launches. */
+int p2p_igemm_norm_act_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+int p2p_igemm_norm_act(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
+                       const void* w, const float* gamma, const float* beta, float eps, int act, float alpha,
+                       const p2p_tensor* act_out, float* stats, void* stream);
 int p2p_brig_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
 int p2p_igemm_layer_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
 
@@ -339,6 +348,19 @@ int p2p_dropout_mask(unsigned char* mask, long long n, long long seed, long long
  * multiple of 8), so the ranks of a data-parallel step draw the masks of the single-process global batch. */
 int p2p_dropout_mask_dev(unsigned char* mask, long long n, long long seed, const long long* counter_dev,
                          long long salt, long long elem_offset, void* stream);
+
+/* ---- collectives (RCCL over xGMI; build-added data parallelism) ----------------------------------- */
+
+/* For hosts without PyTorch (the Python host of this repository reaches the same RCCL through torch.distributed).  Rank 0
+ * obtains 128 opaque bytes with p2p_comm_unique_id and distributes them; every rank (one process per GPU, hipSetDevice done)
+ * calls p2p_comm_init with them.  p2p_comm_allreduce_sum: in-place SUM of n f32 values, stream-ordered -- per step the flat
+ * generator gradient buffer in buckets, the tail [small tensors | discriminator gradients | loss slots] and, for the
+ * histogram model, the one Hellinger scalar between p2p_hellinger_fwd and p2p_hellinger_finish.  librccl.so is loaded on the
+ * first call (no link-time dependency). */
+int p2p_comm_unique_id(void* id_out_128_bytes);
+int p2p_comm_init(const void* id_128_bytes, int rank, int world, void** comm_out);
+int p2p_comm_allreduce_sum(void* comm, float* buf, long long n, void* stream);
+int p2p_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "p2p_conv_direct": [_i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp, _vp, _vp],
     "p2p_igemm": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp, _vp],
+    "p2p_igemm_norm_act": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp, _f, _i, _f, _TP, _vp, _vp],
     "p2p_igemm_edge": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_conv_strip": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp],
     "p2p_conv_fewin": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
@@ -68,10 +69,15 @@ SIGNATURES = {
     "p2p_rgbuv_hist_hellinger_bwd": [_i, _i, _i, _i, _TP, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
     "p2p_softmax_cce_argmax": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _f, _TP, _vp, _vp, _vp, _vp],
     "p2p_argmax_lastdim": [_vp, _ll, _i, _vp, _vp],
+    "p2p_comm_unique_id": [_vp],
+    "p2p_comm_init": [_vp, _i, _i, C.POINTER(_vp)],
+    "p2p_comm_allreduce_sum": [_vp, _vp, _ll, _vp],
+    "p2p_comm_destroy": [_vp],
 }
 SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int), "p2p_view_halo_pixels": ([], C.c_int),
            "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),
            "p2p_brig_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
+           "p2p_igemm_norm_act_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_brig_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_igemm_layer_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_fewin_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),

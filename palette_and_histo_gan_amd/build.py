@@ -12,6 +12,20 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
+def source_fingerprint():
+    """sha256 over everything that decides which kernels a step launches and what they do (csrc/, the C ABI header, the
+    engine).  Counter profiles under profiles/ are stamped with it; bench.py only quotes a profile whose stamp matches the
+    tree it runs from (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    files += [os.path.join(os.path.dirname(HERE), "include", "p2pgan.h"), os.path.join(HERE, "engine.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -46,7 +60,7 @@ def build_library(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -48,6 +48,11 @@ struct BrigArgs {
     int nkc;                 // K chunks (op P: C / 32; op G: 4 planes x C / 32)
     int rot;                 // lane rotation per block row on 16-wide maps (row pitch mod 16)
     int stagger;             // waves 4-7 issue their DMA after their first MFMA group (P2P_BRIG_STAGGER, default on)
+    // fused InstanceNorm + activation (whole images per tile): y = act((x - mean) * rstd * gamma + beta) written to act_out,
+    // (mean, rstd) to norm_stats[N][ncols][2]; the rounded conv output still goes to `out` (the backward pass reads it)
+    const float* gamma; const float* beta; float eps; int act; float alpha;
+    char* act_out; long long act_img; int act_row; int act_ld;
+    float* norm_stats;
     long long in_lo;         // most negative byte offset from `in` that a block gathers: per-lane offsets are unsigned from there
 };
 
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (want_stats && lane < CW) {
+        if ((want_stats || a.act_out != nullptr) && lane < CW) {
             const int sel = a.lgLW == 3 ? (pbi >> 1) : 0;
             const bf16_t* col = (const bf16_t*)pL + lane;
             float t1 = 0.f, t2 = 0.f;
@@ -373,7 +378,8 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
-    if (want_stats) {
+    const bool fuse = a.act_out != nullptr;
+    if (want_stats || fuse) {
         if (lane < CW) {
             stL[((wave * 2 + 0) * CW + lane) * 2 + 0] = s1[0];
             stL[((wave * 2 + 0) * CW + lane) * 2 + 1] = s2[0];
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         // strip per tile.  op P: the four phases (quarters) of a half cover the same channels; op G: each quarter has its own.
         const int nimg = a.lgLW == 3 ? 4 : 1;
         constexpr int NCH = MODE == 1 ? CW : 4 * CW;
+        float* const scL = stL + 8 * 2 * CW * 2;             // [nimg][NCH][2]: scale, shift of the fused normalisation
         for (int e = tid; e < nimg * NCH; e += 512) {
             const int img = e / NCH, ch = e - img * NCH;
             const int c = ch & (CW - 1), qd = ch / CW;       // op G: the quarter that owns the channel
@@ -400,13 +407,72 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
                 }
             }
             const int n = img0 + img;
-            if (n < a.N) {
-                const float cnt = (float)((MODE == 1 ? 4 : 1) * a.rpt * a.LW);
-                const float mean = t1 / cnt;
+            const float cnt = (float)((MODE == 1 ? 4 : 1) * a.rpt * a.LW);
+            const float mean = t1 / cnt;
+            const float m2 = fmaxf(t2 - t1 * mean, 0.f);
+            if (n < a.N && want_stats) {
                 const int slot = a.tiles_per_img > 1 ? tile - img0 * a.tiles_per_img : 0;
                 float* dst = a.stat_part + (((long long)n * a.stat_slots + slot) * a.ncols + n0c + ch) * 2;
                 dst[0] = mean;
-                dst[1] = fmaxf(t2 - t1 * mean, 0.f);
+                dst[1] = m2;
+            }
+            if (fuse) {
+                const float rstd = rsqrtf(m2 / cnt + a.eps);
+                const float ga = a.gamma[n0c + ch] * rstd;
+                scL[(img * NCH + ch) * 2] = ga;
+                scL[(img * NCH + ch) * 2 + 1] = a.beta[n0c + ch] - mean * ga;
+                if (n < a.N) {
+                    a.norm_stats[((long long)n * a.ncols + n0c + ch) * 2] = mean;
+                    a.norm_stats[((long long)n * a.ncols + n0c + ch) * 2 + 1] = rstd;
+                }
+            }
+        }
+        if (fuse) {
+            // second pass over the accumulators: the same rounded values through the patch, normalised and activated on the
+            // way out, into the (haloed, channel-sliced) activation view -- the block is complete without a separate kernel
+            __syncthreads();
+            constexpr int LPP = CW / 8, PPS = 64 / LPP;
+            const int ch8 = lane & (LPP - 1);
+            const int cw0 = (MODE == 1 ? 0 : quarter * CW) + ch8 * 8;     // first of this lane's 8 channels inside the workgroup's range
+#pragma unroll
+            for (int pbi = 0; pbi < 4; ++pbi) {
+                const int pb = half * 4 + pbi;
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 qv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) qv[k] = (bf16_t)acc[pbi][cb][4 * g + k];
+                        *(bf16x4*)(pL + r * PROW + (cb * 32 + 8 * g + 4 * h) * 2) = qv;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 32 / PPS; ++ps) {
+                    const int pix = ps * PPS + lane / LPP;
+                    int img, ly, lx;
+                    brig_lane_pixel(a, pb, pix, img, ly, lx);
+                    const int n = img0 + img;
+                    if (n < a.N) {
+                        const bf16x8 xv = *(const bf16x8*)(pL + pix * PROW + ch8 * 16);
+                        const float* sc = scL + (img * NCH + cw0) * 2;
+                        bf16x8 yv;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float y = (float)xv[k] * sc[2 * k] + sc[2 * k + 1];
+                            if (a.act == P2P_ACT_LEAKY) y = y > 0.f ? y : a.alpha * y;
+                            else if (a.act == P2P_ACT_RELU) y = y > 0.f ? y : 0.f;
+                            yv[k] = (bf16_t)y;
+                        }
+                        long long opix;
+                        if (MODE == 1) opix = (long long)n * a.act_img + (long long)(2 * (y0 + ly) + ph) * a.act_row + (2 * lx + pw);
+                        else opix = (long long)n * a.act_img + (long long)(y0 + ly) * a.act_row + lx;
+                        *(bf16x8*)((bf16_t*)a.act_out + opix * a.act_ld + n0c + cw0) = yv;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -465,7 +531,7 @@ static BrigPlan brig_plan(int op, int dtype, int N, int LH, int LW, int Cg, int 
     p.ring = (ring_env == 4 || ring_env == 6) ? ring_env : 4;      // six stages measured no better than four (r02)
     if (2 * (size_t)p.abytes + (size_t)p.ring * 16384 > 158 * 1024) p.ring = 4;
     p.shm = 2 * (size_t)p.abytes + (size_t)p.ring * 16384;
-    const size_t epi = 8 * 32 * 144 + 8 * 2 * 64 * 2 * sizeof(float);
+    const size_t epi = 8 * 32 * 144 + 8 * 2 * 64 * 2 * sizeof(float) + 4 * 256 * 2 * sizeof(float);
     if (p.shm < epi) p.shm = epi;
     if (p.shm > 160 * 1024) return p;
     p.ok = 1;
@@ -481,8 +547,10 @@ extern "C" int p2p_brig_stat_slots(int op, int dtype, int N, int LH, int LW, int
     return p.ok ? p.slots : 0;
 }
 
+struct BrigNorm { const float* gamma; const float* beta; float eps; int act; float alpha; const p2p_tensor* act_out; float* stats; };
+
 int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
-                const void* w, float* stat_part, void* stream) {
+                const void* w, float* stat_part, void* stream, const BrigNorm* norm = nullptr) {
     const BrigPlan p = brig_plan(op, dtype, N, LH, LW, Cg, Cd);
     P2P_REQUIRE(p.ok, "p2p_brig: shape not supported (query p2p_brig_ok)");
     const p2p_tensor* in = op == P2P_OP_G ? hi : lo;
@@ -502,6 +570,15 @@ int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const 
     a.ipt = p.ipt; a.rpt = p.rpt; a.tiles_per_img = p.tiles_per_img; a.ntiles = p.ntiles; a.nnt = p.nnt;
     a.BR = p.BR; a.PITCH = p.PITCH; a.BP = p.BP; a.npix = p.npix; a.npieces = p.npieces;
     a.abytes = p.abytes; a.nkc = p.nkc; a.rot = p.rot;
+    a.gamma = a.beta = nullptr; a.eps = 0.f; a.act = 0; a.alpha = 0.f; a.act_out = nullptr; a.act_img = 0; a.act_row = a.act_ld = 0; a.norm_stats = nullptr;
+    if (norm) {
+        P2P_REQUIRE(p.tiles_per_img == 1, "p2p_igemm_norm_act: the fused block needs whole images per workgroup (query p2p_igemm_norm_act_ok)");
+        P2P_REQUIRE(norm->gamma && norm->beta && norm->act_out && norm->act_out->ptr && norm->stats, "p2p_igemm_norm_act: null pointer");
+        P2P_REQUIRE((norm->act_out->ld * 2) % 16 == 0 && ((uintptr_t)norm->act_out->ptr % 16) == 0, "p2p_igemm_norm_act: activation view must be 16-byte aligned");
+        a.gamma = norm->gamma; a.beta = norm->beta; a.eps = norm->eps; a.act = norm->act; a.alpha = norm->alpha;
+        a.act_out = (char*)norm->act_out->ptr; a.act_img = norm->act_out->img_stride; a.act_row = norm->act_out->row_stride; a.act_ld = norm->act_out->ld;
+        a.norm_stats = norm->stats;
+    }
     { static int sg = -1; if (sg < 0) { const char* e = getenv("P2P_BRIG_STAGGER"); sg = e ? atoi(e) : 1; } a.stagger = sg; }
     // per-lane gather offsets are 32-bit, counted from the lowest address a block touches (row -1, column -1 of image 0)
     a.in_lo = -((long long)in->row_stride + 1) * in->ld * 2;
@@ -529,4 +606,22 @@ int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const 
     }
 #undef BRIG_GO
     return p2p_check_launch("p2p_igemm(block-resident)");
+}
+
+// Fused block (networks.py:7-21,24-36 without dropout): convolution + InstanceNorm + LeakyReLU / ReLU in one launch, on the
+// shapes whose workgroups hold whole images.  1 if p2p_igemm_norm_act takes the shape.
+extern "C" int p2p_igemm_norm_act_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd) {
+    const BrigPlan p = brig_plan(op, dtype, N, LH, LW, Cg, Cd);
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("P2P_BRIG_FUSE_NORM"); en = e ? atoi(e) : 1; }
+    return p.ok && p.tiles_per_img == 1 && en;
+}
+
+extern "C" int p2p_igemm_norm_act(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi,
+                                  const p2p_tensor* lo, const void* w, const float* gamma, const float* beta, float eps,
+                                  int act, float alpha, const p2p_tensor* act_out, float* stats, void* stream) {
+    P2P_REQUIRE(op == P2P_OP_G || op == P2P_OP_P, "p2p_igemm_norm_act: op must be G or P");
+    P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && w, "p2p_igemm_norm_act: null pointer");
+    BrigNorm nm = {gamma, beta, eps, act, alpha, act_out, stats};
+    return brig_launch(op, dtype, N, LH, LW, Cg, Cd, hi, lo, w, nullptr, stream, &nm);
 }

@@ -530,8 +530,9 @@ extern "C" int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols) {
 // block-resident form for the wide maps (brig.hip)
 extern "C" int p2p_brig_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
 extern "C" int p2p_brig_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
+struct BrigNorm;
 int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
-                const void* w, float* stat_part, void* stream);
+                const void* w, float* stat_part, void* stream, const BrigNorm* norm = nullptr);
 
 // Statistics slots of p2p_igemm for a layer, whichever of its two kernels takes the shape (block-resident form on the
 // wide bf16 maps, im2col form otherwise).

@@ -20,6 +20,7 @@ struct WsArgs {
     int N, LH, LW, Cg, Cd;
     int TH;                        // lo rows per strip
     int strips_per_img, nstrips;   // LH / TH, N * strips_per_img
+    int nbuf, buf_bytes;           // 1 or 2 strip buffers of buf_bytes each (hi strip | lo strip)
     int pack;                      // 0: one tap per MFMA tile row block.  Few-channel sides (8-channel = 16-byte pixels, bf16):
                                    // 1: a hi tile holds 4 taps x 8 hi channels, 2: a lo tile holds 4 taps x 8 lo channels
 };
@@ -46,7 +47,6 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
     const int lpB = lgB > 64 * DT * (ESZ / 2) ? 64 * DT * (ESZ / 2) : lgB;     // LDS bytes per lo pixel
     const int hrowB = RW * hpB;                                  // bytes per strip row in LDS
     const int hi_bytes = RH * hrowB;
-    const int lrowB = TW * lpB;
     char* hiL = smem;
     char* loL = smem + ((hi_bytes + 15) & ~15) + 256;           // slack: short pixels are over-read by up to 64 B
 
@@ -60,10 +60,12 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
 
-    for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x) {
+    // Strips are double-buffered when the plan left room (a.nbuf == 2): the LDS-DMA of strip s+1 is issued before strip s is
+    // contracted and waited for after it, so staging (HBM latency + issue) hides behind the MFMAs instead of alternating with them.
+    const int buf_bytes = a.buf_bytes;
+    auto stage_strip = [&](int strip, char* hiB, char* loB) {
         const int n = strip / a.strips_per_img, y0 = (strip % a.strips_per_img) * TH;
-        __syncthreads();      // previous strip fully consumed
-        // ---- stage the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
+        // ---- the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
         const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row, hcpp = hpB >> 4;
         for (int cI = wave * 64; cI < hchunks; cI += NTHR) {
             int ci = cI + lane;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                 int px = cc / hcpp, ch = cc - px * hcpp;            // pixel of the strip row, 16-byte chunk inside its window
                 const char* src = a.hi + ((long long)n * a.hi_img + (long long)(S * y0 - 1 + rr) * a.hi_row - 1 + px) * hgB +
                                   (hpB == hgB ? 0 : g0 * ESZ) + ch * 16;
-                glds16s(src, hiL + cI * 16);       // wave-uniform base + lane*16
+                glds16s(src, hiB + cI * 16);       // wave-uniform base + lane*16
             }
         }
         const int LWp = a.pack == 2 ? TW + 3 : TW, LHp = a.pack == 2 ? TH + 3 : TH, lo_org = a.pack == 2 ? -2 : 0;
@@ -84,11 +86,21 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                 int px = cc / lcpp, ch = cc - px * lcpp;
                 const char* src = a.lo + ((long long)n * a.lo_img + (long long)(y0 + lo_org + rr) * a.lo_row + lo_org + px) * lgB +
                                   (lpB == lgB ? 0 : d0 * ESZ) + ch * 16;
-                glds16s(src, loL + cI * 16);
+                glds16s(src, loB + cI * 16);
             }
         }
+    };
+    int cur = 0;
+    if ((int)blockIdx.x < a.nstrips) stage_strip(blockIdx.x, hiL, loL);
+    for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();      // this strip has landed; the other buffer (previous strip) is fully consumed
+        if (a.nbuf == 2) {
+            const int nxt = strip + gridDim.x;
+            if (nxt < a.nstrips) stage_strip(nxt, smem + (cur ^ 1) * buf_bytes, smem + (cur ^ 1) * buf_bytes + (loL - hiL));
+        }
+        char* const hiC = smem + cur * buf_bytes;
+        char* const loC = hiC + (loL - hiL);
         // ---- contract: k-steps of 16 (bf16) / 2 (f32) consecutive lo pixels of one row -------------------------------
         if constexpr (ESZ == 2) {
             const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
@@ -115,8 +127,8 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                                 offh = ((yy + 1) * RW + x + 1) * hpB + tsel * 64 + chB;
                                 offl = ((yy - kh + 3) * (TW + 3) + (x - kw + 3)) * lpB + chP;
                             }
-                            rh[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiL + offh));
-                            rl[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loL + offl));
+                            rh[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiC + offh));
+                            rl[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loC + offl));
                         }
                         union { s16x4 h[2]; bf16x8 v; } uh, ul;
                         uh.h[0] = rh[0]; uh.h[1] = rh[1];
@@ -124,8 +136,7 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                         acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh.v, ul.v, acc[0][0][0], 0, 0, 0);
                     }
                 }
-                continue;
-            }
+            } else
             for (int yy = 0; yy < TH; ++yy) {
                 for (int x0 = 0; x0 < TW; x0 += 16) {
                     bf16x8 bfr[DT];
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                         for (int rd = 0; rd < 2; ++rd) {
                             int x = x0 + 8 * (grp >> 1) + 4 * rd + q;
                             int off = (yy * TW + x) * lpB + j * 64 + chB;
-                            r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loL + off));
+                            r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loC + off));
                         }
                         union { s16x4 h[2]; bf16x8 v; } u;
                         u.h[0] = r[0]; u.h[1] = r[1];
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                             for (int rd = 0; rd < 2; ++rd) {
                                 int x = x0 + 8 * (grp >> 1) + 4 * rd + q;
                                 int off = ((S * yy + kh) * RW + S * x + kw) * hpB + i * 64 + chB;
-                                r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiL + off));
+                                r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiC + off));
                             }
                             union { s16x4 h[2]; bf16x8 v; } u;
                             u.h[0] = r[0]; u.h[1] = r[1];
@@ -170,13 +181,13 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                     const int x = x0 + kl;
                     float bfr[DT];
 #pragma unroll
-                    for (int j = 0; j < DT; ++j) bfr[j] = *(const float*)(loL + (yy * TW + x) * lpB + (j * 32 + cl) * 4);
+                    for (int j = 0; j < DT; ++j) bfr[j] = *(const float*)(loC + (yy * TW + x) * lpB + (j * 32 + cl) * 4);
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) {
                         const int tap = wave * TPW + t, kh = tap >> 2, kw = tap & 3;
 #pragma unroll
                         for (int i = 0; i < GT; ++i) {
-                            float af = *(const float*)(hiL + ((S * yy + kh) * RW + S * x + kw) * hpB + (i * 32 + cl) * 4);
+                            float af = *(const float*)(hiC + ((S * yy + kh) * RW + S * x + kw) * hpB + (i * 32 + cl) * 4);
 #pragma unroll
                             for (int j = 0; j < DT; ++j)
                                 acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bfr[j], acc[t][i][j], 0, 0, 0);
@@ -184,6 +195,11 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                     }
                 }
             }
+        }
+            if (a.nbuf == 2) cur ^= 1;
+        else {
+            const int nxt = strip + gridDim.x;
+            if (nxt < a.nstrips) { __syncthreads(); stage_strip(nxt, hiL, loL); }     // single buffer: every wave is done with the strip
         }
     }
     // ---- partial store: D[row = g][col = d] ------------------------------------------------------------------------
@@ -267,10 +283,10 @@ static int ws_waves16() {
 }
 
 // Tiling of the LDS-resident form: 32x32 MFMA tiles per workgroup (GT x DT <= 4), channel windows, strip height.
-struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks, pack; size_t shm; };
+struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks, pack, nbuf, buf_bytes; size_t shm; };
 
 static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
-    WsPlan p = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    WsPlan p = {};
     const int esz = dtype == P2P_BF16 ? 2 : 4;
     if ((LW & (LW - 1)) || LW < 16 || LW > 64) return p;
     if ((hi_ld * esz) % 16 || (lo_ld * esz) % 16) return p;
@@ -287,22 +303,36 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
         if (hi_ld == 8 && Cg <= 8 && p.GT == 1 && p.DT == 2) p.pack = 1;                       // 4/8 -> 64 (down1, D.down)
         else if (stride == 1 && lo_ld == 8 && Cd <= 8 && p.GT == 2 && p.DT == 1) p.pack = 2;   // 36 -> 4, 64 -> 1 (the heads)
     }
+    // strip height: the tallest of 8, 4, 2, 1 rows (<= 512 pixels) whose TWO buffers fit 150 KB (staging of the next strip under
+    // the MFMAs of this one), unless that would leave strips of a single row where a single buffer allows >= 4 rows
+    static int dbuf = -1;
+    if (dbuf < 0) { const char* e = getenv("P2P_WS_DBUF"); dbuf = e ? atoi(e) : 0; }     // measured slower on c2 (r02: shorter strips, more halo): off
+    auto bytes_for = [&](int th) {
+        const size_t hpB = (size_t)hi_ld * esz > (size_t)64 * p.GT * (esz / 2) ? (size_t)64 * p.GT * (esz / 2) : (size_t)hi_ld * esz;
+        const size_t lpB = (size_t)lo_ld * esz > (size_t)64 * p.DT * (esz / 2) ? (size_t)64 * p.DT * (esz / 2) : (size_t)lo_ld * esz;
+        const size_t hi_bytes = (size_t)(stride * th + 3) * (stride * LW + 3) * hpB;
+        const size_t lo_bytes = p.pack == 2 ? (size_t)(th + 3) * (LW + 3) * lpB : (size_t)th * LW * lpB;
+        return ((hi_bytes + 15) & ~(size_t)15) + 256 + ((lo_bytes + 15) & ~(size_t)15) + 512;
+    };
     int TH = 512 / LW;
     if (TH > 8) TH = 8;
     if (TH > LH) TH = LH;
-    for (;; TH >>= 1) {
-        if (TH < 1 || LH % TH) return p;
-        const size_t hpB = (size_t)hi_ld * esz > (size_t)64 * p.GT * (esz / 2) ? (size_t)64 * p.GT * (esz / 2) : (size_t)hi_ld * esz;
-        const size_t lpB = (size_t)lo_ld * esz > (size_t)64 * p.DT * (esz / 2) ? (size_t)64 * p.DT * (esz / 2) : (size_t)lo_ld * esz;
-        const size_t hi_bytes = (size_t)(stride * TH + 3) * (stride * LW + 3) * hpB;
-        const size_t lo_bytes = p.pack == 2 ? (size_t)(TH + 3) * (LW + 3) * lpB : (size_t)TH * LW * lpB;
-        p.shm = ((hi_bytes + 15) & ~(size_t)15) + 256 + lo_bytes + 512;
-        if (p.shm <= 150 * 1024) break;
-        if (TH == 1) return p;
+    int th1 = 0, th2 = 0;       // tallest strip with one / two buffers
+    for (int t = TH; t >= 1; t >>= 1) {
+        if (LH % t) continue;
+        if (!th1 && bytes_for(t) <= 150 * 1024) th1 = t;
+        if (!th2 && 2 * bytes_for(t) <= 150 * 1024) th2 = t;
     }
+    if (!th1) return p;
+    p.nbuf = (dbuf && th2 && (th2 >= 2 || th1 < 4)) ? 2 : 1;
+    TH = p.nbuf == 2 ? th2 : th1;
+    p.buf_bytes = (int)bytes_for(TH);
+    p.shm = (size_t)p.nbuf * p.buf_bytes;
     p.TH = TH;
     long long strips = (long long)N * (LH / TH);
-    long long want = 512 / (p.gwins * p.dwins);
+    static int want_env = -1;
+    if (want_env < 0) { const char* e = getenv("P2P_WS_WANT"); want_env = e ? atoi(e) : 256;     // one workgroup per CU: half the partial slabs of 512, c2 step 1 % faster (r02) }
+    long long want = want_env / (p.gwins * p.dwins);
     const long long slab_bytes = 16LL * Cg * Cd * 4;
     const long long cap = (64LL << 20) / slab_bytes;         // keep the partial slabs within 64 MB
     if (want > cap) want = cap;
@@ -365,6 +395,7 @@ extern "C" int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int
     (void)esz;
     a.TH = plan.TH;
     a.pack = plan.pack;
+    a.nbuf = plan.nbuf; a.buf_bytes = plan.buf_bytes;
     a.strips_per_img = LH / plan.TH;
     a.nstrips = N * a.strips_per_img;
     hipStream_t st = (hipStream_t)stream;

@@ -567,6 +567,18 @@ class Pix2PixEngine:
                    self._wd(sid, name), bias if bias is not None else NULL, NULL, NULL, _stream())
         return (1, 1)
 
+    def _fused_block(self, P, op, name, N, lh, in_view, raw_buf, act, out_view, stats):
+        """Convolution + InstanceNorm + activation of one generator block in one launch (p2p_igemm_norm_act) where the shape
+        qualifies (bf16, workgroups that hold whole images): returns False otherwise and the caller issues the two launches."""
+        lw = self.W[("G", name)]
+        if not (self.use_mfma and lw.main and L.lib().p2p_igemm_norm_act_ok(op, self.dtype, N, lh, lh, lw.cg, lw.cd)):
+            return False
+        hi, lo = (in_view, raw_buf.view()) if op == L.OP_G else (raw_buf.view(), in_view)
+        w = _p(lw.wt) if op == L.OP_G else self._wn("G", name)
+        L.call("p2p_igemm_norm_act", op, self.dtype, N, lh, lh, lw.cg, lw.cd, C.byref(hi), C.byref(lo), w,
+               self.G.p(name + ".gamma"), self.G.p(name + ".beta"), IN_EPS, act, LEAKY_ALPHA, C.byref(out_view), _p(stats), _stream())
+        return True
+
     def _wgrad(self, P, sid, name, N, lh, hi, lo, stride=2, dbias=None):
         """dW (and dbias) of one layer, issued on the side stream: its inputs were produced on the main stream
         before this call (fork), its outputs are only read by Adam (join in _finish_step)."""
@@ -732,6 +744,8 @@ class Pix2PixEngine:
             out_view = P["a6"].view() if i == 6 else c[6 - i].view(coff=UP_FILTERS[5 - i])
             if i == 1:      # no norm (networks.py:58): LeakyReLU fused in the conv epilogue
                 self._conv(P, L.OP_G, "G", "down1", B, res, src_view, out_view, act=L.ACT_LEAKY, tmp=P["rd"].get(1))
+            elif self._fused_block(P, L.OP_G, f"down{i}", B, res, src_view, P["rd"][i], L.ACT_LEAKY, out_view, P["sd"][i]):
+                pass
             else:
                 rk = self._conv(P, L.OP_G, "G", f"down{i}", B, res, src_view, P["rd"][i].view(), want_stats=True)
                 self._norm_fwd(P, B, res, f, P["rd"][i], rk, self.G.p(f"down{i}.gamma"), self.G.p(f"down{i}.beta"),
@@ -741,6 +755,10 @@ class Pix2PixEngine:
         lo_view = P["a6"].view()
         for i, f in enumerate(UP_FILTERS, start=1):
             lh = S // 64 * 2 ** (i - 1)
+            if not UP_DROPOUT[i - 1] and self._fused_block(P, L.OP_P, f"up{i}", B, lh, lo_view, P["ru"][i], L.ACT_RELU,
+                                                           c[i].view(coff=0), P["su"][i]):
+                lo_view = c[i].view()
+                continue
             rk = self._conv(P, L.OP_P, "G", f"up{i}", B, lh, lo_view, P["ru"][i].view(), want_stats=True)
             mask = None
             if UP_DROPOUT[i - 1]:

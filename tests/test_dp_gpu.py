@@ -130,3 +130,23 @@ def test_world1_rccl_step_matches_plain_step(tmp_path, monkeypatch):
         assert np.isfinite(ref[0]).all()
     finally:
         comm.destroy()
+
+
+def test_c_abi_collective_world1():
+    """include/p2pgan.h p2p_comm_*: RCCL reached through the C ABI alone (a host without PyTorch binds these); on the one-GPU
+    test box a world of one rank: SUM all-reduce = identity, stream-ordered."""
+    import ctypes as C
+    from palette_and_histo_gan_amd import _lib as L
+    ident = (C.c_char * 128)()
+    L.call("p2p_comm_unique_id", C.cast(ident, C.c_void_p))
+    comm = C.c_void_p()
+    L.call("p2p_comm_init", C.cast(ident, C.c_void_p), 0, 1, C.byref(comm))
+    try:
+        x = torch.arange(1 << 20, dtype=torch.float32, device="cuda:0")
+        want = x.clone()
+        st = torch.cuda.current_stream()
+        L.call("p2p_comm_allreduce_sum", comm, C.c_void_p(x.data_ptr()), x.numel(), C.c_void_p(st.cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(x, want)
+    finally:
+        L.call("p2p_comm_destroy", comm)

@@ -576,6 +576,48 @@ def test_igemm_block_resident_wide_maps(op, n, lh, cg, cd, cbw, monkeypatch):
     assert np.array_equal(back[..., 64:], got) and not back[..., :64].any()
 
 
+@pytest.mark.parametrize("cbw", [1, 2])
+@pytest.mark.parametrize("op,n,lh,cg,cd,act", [(L.OP_P, 5, 8, 128, 64, L.ACT_RELU), (L.OP_P, 2, 16, 64, 96, L.ACT_RELU),
+                                               (L.OP_G, 3, 8, 64, 256, L.ACT_LEAKY), (L.OP_G, 2, 16, 32, 256, L.ACT_LEAKY)])
+def test_fused_block_conv_instance_norm_activation(op, n, lh, cg, cd, act, cbw, monkeypatch):
+    """One launch for the whole block of networks.py:7-21 / 24-36 (without dropout): the activated output, the raw
+    convolution result and the (mean, rstd) statistics equal convolution + p2p_norm_act_fwd in two launches and the oracle."""
+    dtype = L.BF16
+    monkeypatch.setenv("P2P_BRIG_CBW", str(cbw))
+    assert L.lib().p2p_igemm_norm_act_ok(op, dtype, n, lh, lh, cg, cd) == 1
+    assert L.lib().p2p_igemm_norm_act_ok(L.OP_P, dtype, n, 32, 32, 64, 64) == 0        # strips of an image: not fusable
+    rng = np.random.default_rng(29)
+    hi, lo, w = make_case(rng, n, lh, cg, cd, 2, dtype)
+    g_ref, p_ref, _ = oracle_ops(hi, lo, w, 2)
+    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
+    wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    w_d = U.dev(w.reshape(-1))
+    L.call("p2p_weight_prep", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
+    ref, shape = (g_ref, (n, lh, lh, cd)) if op == L.OP_G else (p_ref, (n, 2 * lh, 2 * lh, cg))
+    ncols, res = shape[3], shape[1]
+    gamma = (1 + 0.2 * rng.normal(size=ncols)).astype(np.float32)
+    beta = (0.2 * rng.normal(size=ncols)).astype(np.float32)
+    g_d, b_d = U.dev(gamma), U.dev(beta)
+    raw = E.DenseBuf(*shape, U.tdt(dtype), U.DEV)
+    raw.t.fill_(float("nan"))
+    y = E.HaloBuf(n, res, res, ncols + 32, dtype, U.DEV)
+    stats = torch.full((n, ncols, 2), float("nan"), dtype=torch.float32, device=U.DEV)
+    hv, lv = (hi_b.view(), raw.view()) if op == L.OP_G else (raw.view(), lo_b.view())
+    L.call("p2p_igemm_norm_act", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn),
+           U.ptr(g_d), U.ptr(b_d), 1e-3, act, 0.3, C.byref(y.view(coff=32)), U.ptr(stats), U.stream())
+    x = U.dense_to_np(raw).astype(np.float64)
+    assert U.rel_err(x, ref) < OUT_TOL[dtype]
+    mean, var = x.mean(axis=(1, 2)), x.var(axis=(1, 2))
+    np.testing.assert_allclose(stats[..., 0].cpu().numpy(), mean, rtol=1e-4, atol=1e-5 * np.abs(x).max())
+    np.testing.assert_allclose(stats[..., 1].cpu().numpy(), 1.0 / np.sqrt(var + 1e-3), rtol=3e-4)
+    z = rg.instance_norm(torch.tensor(x), torch.tensor(gamma, dtype=F64), torch.tensor(beta, dtype=F64))
+    want = (torch.relu(z) if act == L.ACT_RELU else rg.leaky_relu(z)).numpy()
+    got = U.halo_to_np(y)
+    assert U.rel_err(got[..., 32:], want) < OUT_TOL[dtype]
+    assert not got[..., :32].any()           # the other slice of the concat buffer is untouched
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,stride", [(3, 32, 4, 64, 2), (2, 32, 8, 64, 2), (2, 64, 36, 4, 1), (3, 32, 64, 1, 1),
                                                 (2, 16, 1, 64, 2), (20, 64, 33, 8, 1), (3, 32, 32, 128, 2), (2, 16, 64, 128, 2),

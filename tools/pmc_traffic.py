@@ -12,7 +12,7 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = {"igemm_kernel": "p2p_igemm", "wgemm_kernel": "p2p_wgemm", "norm_act_fwd_vec": "p2p_norm_act_fwd",
+FAMILIES = {"igemm_kernel": "p2p_igemm", "brig_kernel": "p2p_igemm", "wgemm_kernel": "p2p_wgemm", "norm_act_fwd_vec": "p2p_norm_act_fwd",
             "norm_act_bwd_vec": "p2p_norm_act_bwd", "adam_flat_dev_kernel": "p2p_adam_flat_dev",
             "weight_prep_kernel": "p2p_weight_prep_pad", "rgbuv_hist_fwd_kernel": "p2p_rgbuv_hist_fwd",
             "rgbuv_hist_bwd_kernel": "p2p_rgbuv_hist_hellinger_bwd"}
@@ -42,6 +42,9 @@ def load(folder, counter):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    config = sys.argv[4] if len(sys.argv) > 4 else "c2"
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from palette_and_histo_gan_amd.build import source_fingerprint
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     res = {}
     for fam in sorted(set(fetch) | set(write)):
@@ -52,8 +55,10 @@ def main():
                     "write_bytes_per_launch": (w / nw) * 1024 if nw else None}
         if nf and nw:
             res[fam]["hbm_bytes_per_launch"] = res[fam]["fetch_bytes_per_launch"] + res[fam]["write_bytes_per_launch"]
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --config c2, "
-                         "KiB units, FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)", "kernels": res}, open(out, "w"), indent=1)
+    commit = os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip()
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --config {config}, "
+                         "KiB units, FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)",
+               "fingerprint": source_fingerprint(), "commit": commit, "kernels": res}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
