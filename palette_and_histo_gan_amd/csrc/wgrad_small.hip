@@ -330,8 +330,9 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     p.shm = (size_t)p.nbuf * p.buf_bytes;
     p.TH = TH;
     long long strips = (long long)N * (LH / TH);
+    // workgroups wanted per launch: one per CU -- half the partial slabs of 512, c2 step 1 % faster (r02)
     static int want_env = -1;
-    if (want_env < 0) { const char* e = getenv("P2P_WS_WANT"); want_env = e ? atoi(e) : 256;     // one workgroup per CU: half the partial slabs of 512, c2 step 1 % faster (r02) }
+    if (want_env < 0) { const char* e = getenv("P2P_WS_WANT"); want_env = e ? atoi(e) : 256; }
     long long want = want_env / (p.gwins * p.dwins);
     const long long slab_bytes = 16LL * Cg * Cd * 4;
     const long long cap = (64LL << 20) / slab_bytes;         // keep the partial slabs within 64 MB
