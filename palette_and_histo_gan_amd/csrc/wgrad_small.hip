@@ -21,6 +21,9 @@ struct WsArgs {
     int TH;                        // lo rows per strip
     int strips_per_img, nstrips;   // LH / TH, N * strips_per_img
     int nbuf, buf_bytes;           // 1 or 2 strip buffers of buf_bytes each (hi strip | lo strip)
+    int hrowB, lo_off;             // LDS bytes per hi strip row (a multiple of 256 when swizzled), offset of the lo strip in a buffer
+    int abl;                       // diagnostics (P2P_WS_ABL): 1 = staging only, 2 = contraction only (results wrong)
+    int mh, ml;                    // bank swizzle masks of the hi / lo strip (0 = natural order), see ws_swz
     int pack;                      // 0: one tap per MFMA tile row block.  Few-channel sides (8-channel = 16-byte pixels, bf16):
                                    // 1: a hi tile holds 4 taps x 8 hi channels, 2: a lo tile holds 4 taps x 8 lo channels
 };
@@ -29,6 +32,14 @@ __device__ __forceinline__ void glds16s(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+
+// Bank swizzle of a strip.  One ds_read_b64_tr_b16 lane group (32 lanes) reads 4 pixels x 64 bytes; the pixels are
+// u = (pixel bytes x pixel step) / 64 LDS "quarters" (64 B = 16 banks) apart, so for u = 2 / 4 they share 2 / 1 of the 4
+// quarters of the 256-byte bank line: 2- / 4-way conflicts (r02 PMC: 60 % of this kernel's LDS cycles were conflict cycles).
+// The quarter index (byte bits 6-7) is therefore XORed with the next bits (8-9) masked by m = u - 1 (checked exhaustively
+// for every start pixel: conflict-free for (64 B, step 2) m=1, (128, 2) m=3, (128, 1) m=1, (256, 1) m=3).  The LDS-DMA
+// writes lane-linear, so the stager applies the same involution to the SOURCE chunk index.
+__device__ __forceinline__ int ws_swz(int b, int m) { return b ^ (((b >> 8) & m) << 6); }
 
 template <typename T, int S, int GT, int DT, int TPW>
 __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
@@ -45,10 +56,10 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
     const int g0 = blockIdx.z * 32 * GT, d0 = blockIdx.y * 32 * DT;
     const int hpB = hgB > 64 * GT * (ESZ / 2) ? 64 * GT * (ESZ / 2) : hgB;     // LDS bytes per hi pixel
     const int lpB = lgB > 64 * DT * (ESZ / 2) ? 64 * DT * (ESZ / 2) : lgB;     // LDS bytes per lo pixel
-    const int hrowB = RW * hpB;                                  // bytes per strip row in LDS
-    const int hi_bytes = RH * hrowB;
+    const int hrowB = a.hrowB;                                   // bytes per strip row in LDS
+    const int mh = a.mh, ml = a.ml;
     char* hiL = smem;
-    char* loL = smem + ((hi_bytes + 15) & ~15) + 256;           // slack: short pixels are over-read by up to 64 B
+    char* loL = smem + a.lo_off;                                 // behind the hi strip + slack: short pixels are over-read by up to 64 B
 
     f32x16 acc[TPW][GT][DT];
 #pragma unroll
@@ -64,6 +75,7 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
     // contracted and waited for after it, so staging (HBM latency + issue) hides behind the MFMAs instead of alternating with them.
     const int buf_bytes = a.buf_bytes;
     auto stage_strip = [&](int strip, char* hiB, char* loB) {
+        if (a.abl == 2) return;
         const int n = strip / a.strips_per_img, y0 = (strip % a.strips_per_img) * TH;
         // ---- the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
         const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row, hcpp = hpB >> 4;
@@ -71,7 +83,9 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
             int ci = cI + lane;
             if (ci < hchunks) {
                 int rr = ci / hchunks_row, cc = ci - rr * hchunks_row;
+                cc ^= ((cc >> 4) & mh) << 2;                        // swizzled strips: this slot holds the chunk ws_swz maps here
                 int px = cc / hcpp, ch = cc - px * hcpp;            // pixel of the strip row, 16-byte chunk inside its window
+                if (px >= RW) px = RW - 1;                          // row padding of a swizzled strip (never read)
                 const char* src = a.hi + ((long long)n * a.hi_img + (long long)(S * y0 - 1 + rr) * a.hi_row - 1 + px) * hgB +
                                   (hpB == hgB ? 0 : g0 * ESZ) + ch * 16;
                 glds16s(src, hiB + cI * 16);       // wave-uniform base + lane*16
@@ -82,7 +96,8 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
         for (int cI = wave * 64; cI < lchunks; cI += NTHR) {
             int ci = cI + lane;
             if (ci < lchunks) {
-                int rr = ci / lchunks_row, cc = ci - rr * lchunks_row;
+                const int cs = ci ^ (((ci >> 4) & ml) << 2);
+                int rr = cs / lchunks_row, cc = cs - rr * lchunks_row;
                 int px = cc / lcpp, ch = cc - px * lcpp;
                 const char* src = a.lo + ((long long)n * a.lo_img + (long long)(y0 + lo_org + rr) * a.lo_row + lo_org + px) * lgB +
                                   (lpB == lgB ? 0 : d0 * ESZ) + ch * 16;
@@ -102,7 +117,8 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
         char* const hiC = smem + cur * buf_bytes;
         char* const loC = hiC + (loL - hiL);
         // ---- contract: k-steps of 16 (bf16) / 2 (f32) consecutive lo pixels of one row -------------------------------
-        if constexpr (ESZ == 2) {
+        if (a.abl == 1) {
+        } else if constexpr (ESZ == 2) {
             const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
             const int chB = (16 * (grp & 1) + 4 * p) * 2;            // byte offset of this lane's 4 channels inside a 32-channel tile
             if (a.pack) {
@@ -136,35 +152,44 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                         acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh.v, ul.v, acc[0][0][0], 0, 0, 0);
                     }
                 }
-            } else
+            } else {
+            // per-lane offsets of the reads of one 16-pixel K step at x0 = 0 of a row, swizzled once: a step of 16 pixels and a
+            // row are multiples of 1024 bytes whenever a mask is set, so they do not change the swizzle bits
+            int hb[TPW][GT][2], lb[DT][2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int xl = 8 * (grp >> 1) + 4 * rd + q;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int i = 0; i < GT; ++i) hb[t][i][rd] = ws_swz((S * xl + ((wave * TPW + t) & 3)) * hpB + i * 64 + chB, mh);
+#pragma unroll
+                for (int j = 0; j < DT; ++j) lb[j][rd] = ws_swz(xl * lpB + j * 64 + chB, ml);
+            }
             for (int yy = 0; yy < TH; ++yy) {
                 for (int x0 = 0; x0 < TW; x0 += 16) {
                     bf16x8 bfr[DT];
+                    const int lbase = (yy * TW + x0) * lpB;
 #pragma unroll
                     for (int j = 0; j < DT; ++j) {
                         s16x4 r[2];
 #pragma unroll
-                        for (int rd = 0; rd < 2; ++rd) {
-                            int x = x0 + 8 * (grp >> 1) + 4 * rd + q;
-                            int off = (yy * TW + x) * lpB + j * 64 + chB;
-                            r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loC + off));
-                        }
+                        for (int rd = 0; rd < 2; ++rd)
+                            r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(loC + lbase + lb[j][rd]));
                         union { s16x4 h[2]; bf16x8 v; } u;
                         u.h[0] = r[0]; u.h[1] = r[1];
                         bfr[j] = u.v;
                     }
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) {
-                        const int tap = wave * TPW + t, kh = tap >> 2, kw = tap & 3;
+                        const int tap = wave * TPW + t, kh = tap >> 2;
+                        const int hbase = (S * yy + kh) * hrowB + x0 * S * hpB;
 #pragma unroll
                         for (int i = 0; i < GT; ++i) {
                             s16x4 r[2];
 #pragma unroll
-                            for (int rd = 0; rd < 2; ++rd) {
-                                int x = x0 + 8 * (grp >> 1) + 4 * rd + q;
-                                int off = ((S * yy + kh) * RW + S * x + kw) * hpB + i * 64 + chB;
-                                r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiC + off));
-                            }
+                            for (int rd = 0; rd < 2; ++rd)
+                                r[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hiC + hbase + hb[t][i][rd]));
                             union { s16x4 h[2]; bf16x8 v; } u;
                             u.h[0] = r[0]; u.h[1] = r[1];
 #pragma unroll
@@ -173,6 +198,7 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                         }
                     }
                 }
+            }
             }
         } else {
             const int kl = lane >> 5, cl = lane & 31;
@@ -283,7 +309,7 @@ static int ws_waves16() {
 }
 
 // Tiling of the LDS-resident form: 32x32 MFMA tiles per workgroup (GT x DT <= 4), channel windows, strip height.
-struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks, pack, nbuf, buf_bytes; size_t shm; };
+struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks, pack, nbuf, buf_bytes, hrowB, lo_off, mh, ml; size_t shm; };
 
 static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
     WsPlan p = {};
@@ -307,12 +333,24 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     // the MFMAs of this one), unless that would leave strips of a single row where a single buffer allows >= 4 rows
     static int dbuf = -1;
     if (dbuf < 0) { const char* e = getenv("P2P_WS_DBUF"); dbuf = e ? atoi(e) : 0; }     // measured slower on c2 (r02: shorter strips, more halo): off
+    const size_t hpB = (size_t)hi_ld * esz > (size_t)64 * p.GT * (esz / 2) ? (size_t)64 * p.GT * (esz / 2) : (size_t)hi_ld * esz;
+    const size_t lpB = (size_t)lo_ld * esz > (size_t)64 * p.DT * (esz / 2) ? (size_t)64 * p.DT * (esz / 2) : (size_t)lo_ld * esz;
+    // bank swizzle (ws_swz) of the transposing reads: bf16, unpacked tiles, whole 64-byte quarters per pixel
+    static int swz_on = -1;
+    if (swz_on < 0) { const char* e = getenv("P2P_WS_SWIZZLE"); swz_on = e ? atoi(e) : 1; }
+    auto mask_for = [&](size_t pixB, int step) {
+        if (!swz_on || esz != 2 || p.pack || (pixB != 64 && pixB != 128 && pixB != 256)) return 0;
+        const size_t u = pixB * step / 64;
+        return u == 2 ? 1 : (u == 4 ? 3 : 0);
+    };
+    p.mh = mask_for(hpB, stride);
+    p.ml = mask_for(lpB, 1);
+    p.hrowB = (int)((size_t)(stride * LW + 3) * hpB);
+    if (p.mh) p.hrowB = (p.hrowB + 255) & ~255;
+    auto hi_bytes_for = [&](int th) { return (((size_t)(stride * th + 3) * p.hrowB + 255) & ~(size_t)255) + 256; };
     auto bytes_for = [&](int th) {
-        const size_t hpB = (size_t)hi_ld * esz > (size_t)64 * p.GT * (esz / 2) ? (size_t)64 * p.GT * (esz / 2) : (size_t)hi_ld * esz;
-        const size_t lpB = (size_t)lo_ld * esz > (size_t)64 * p.DT * (esz / 2) ? (size_t)64 * p.DT * (esz / 2) : (size_t)lo_ld * esz;
-        const size_t hi_bytes = (size_t)(stride * th + 3) * (stride * LW + 3) * hpB;
         const size_t lo_bytes = p.pack == 2 ? (size_t)(th + 3) * (LW + 3) * lpB : (size_t)th * LW * lpB;
-        return ((hi_bytes + 15) & ~(size_t)15) + 256 + ((lo_bytes + 15) & ~(size_t)15) + 512;
+        return hi_bytes_for(th) + ((lo_bytes + 255) & ~(size_t)255) + 512;
     };
     int TH = 512 / LW;
     if (TH > 8) TH = 8;
@@ -327,6 +365,7 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     p.nbuf = (dbuf && th2 && (th2 >= 2 || th1 < 4)) ? 2 : 1;
     TH = p.nbuf == 2 ? th2 : th1;
     p.buf_bytes = (int)bytes_for(TH);
+    p.lo_off = (int)hi_bytes_for(TH);
     p.shm = (size_t)p.nbuf * p.buf_bytes;
     p.TH = TH;
     long long strips = (long long)N * (LH / TH);
@@ -397,6 +436,10 @@ extern "C" int p2p_wgrad_small(int dtype, int stride, int N, int LH, int LW, int
     a.TH = plan.TH;
     a.pack = plan.pack;
     a.nbuf = plan.nbuf; a.buf_bytes = plan.buf_bytes;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("P2P_WS_ABL"); abl = e ? atoi(e) : 0; }
+    a.abl = abl;
+    a.hrowB = plan.hrowB; a.lo_off = plan.lo_off; a.mh = plan.mh; a.ml = plan.ml;
     a.strips_per_img = LH / plan.TH;
     a.nstrips = N * a.strips_per_img;
     hipStream_t st = (hipStream_t)stream;
