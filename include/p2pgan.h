@@ -362,6 +362,24 @@ int p2p_comm_init(const void* id_128_bytes, int rank, int world, void** comm_out
 int p2p_comm_allreduce_sum(void* comm, float* buf, long long n, void* stream);
 int p2p_comm_destroy(void* comm);
 
+/* ---- input pipeline (reference dataset_utils.py:11-20,39-49,66-120,209-246) ---------------------------- */
+
+/* Host helper (no GPU): undo the PNG scanline filters of an inflated IDAT stream (height rows of 1 + row_bytes bytes, 8-bit
+ * samples, bpp bytes per pixel) into out[height][row_bytes].  Replaces libpng behind tf.image.decode_png (dataset_utils.py:68). */
+int p2p_png_unfilter(const unsigned char* filtered, int height, int row_bytes, int bpp, unsigned char* out);
+
+/* One RGBA train/test batch from the HBM-resident sprite set `sprites` (uint8 [n_sprites][S][S][4], S a power of two).
+ * src_idx/tgt_idx: device int32 [B] sprite numbers; aug: device f32 [B][4] = (apply != 0, hue delta in turns, dy, dx in
+ * pixels) or NULL (test set / augment=False).  Per pixel: translate (nearest, fill 0) -> blacken alpha == 0
+ * (dataset_utils.py:11-20) -> hue rotation of RGB (tf.image.adjust_hue semantics, :80-84) -> x / 127.5 - 1 if `normalise`
+ * (:39-49) -> source/target f32 [B][S][S][4], the two tensors train_step takes (pix2pix_model.py:63-64). */
+int p2p_sprites_rgba_batch(const void* sprites, int n_sprites, int S, const int* src_idx, const int* tgt_idx, const float* aug,
+                           int B, int normalise, float* source, float* target, void* stream);
+
+/* Row gather out[b] = table[sel[b]] (rows of row_ints int32, row_ints % 4 == 0): indexed batches are rows of the index maps
+ * and palettes extracted once at load time (dataset_utils.py:123-164). */
+int p2p_gather_rows_i32(const int* table, int n_rows, int row_ints, const int* sel, int B, int* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

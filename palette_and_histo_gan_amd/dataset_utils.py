@@ -1,13 +1,23 @@
 """Batch sources with the small slice of the tf.data API that the reference's training loop relies on
 (side2side_model.py:73 `.repeat().take(n).enumerate()`, pix2pix_model.py:107-108 `.unbatch().take(n).batch(1)`,
-`.as_numpy_iterator()`).  The PNG pipeline of the reference (dataset_utils.py:66-246) is out of scope for this round
-(SURVEY.md 8f F1); the value contract of what train_step receives is kept: RGBA batches are (source, target) f32
-(B,S,S,4) in [-1,1] with transparent pixels at -1, indexed batches are (source_idx, target_idx, palette) int32."""
+`.as_numpy_iterator()`), and the sprite input pipeline of the reference (dataset_utils.py:66-246):
+
+    load_rgba_ds(source_direction, target_direction, augment=True)        dataset_utils.py:209-229
+    load_indexed_ds(source_direction, target_direction, palette_ordering) dataset_utils.py:232-246
+
+MI355X-first layout: the sprite set is tiny (19 MB decoded), so it is decoded once (png.py) and kept in HBM; a batch is ONE
+kernel launch (csrc/sprites.hip: gather of the shuffled pair, blacken, shared hue rotation + translation with probability
+0.8, normalise) that writes the f32 tensors train_step takes -- no host worker pool, no per-step PCIe traffic beyond the
+B x 6 numbers that select and augment the batch.  The value contract of what train_step receives is the reference's: RGBA
+batches are (source, target) f32 (B,S,S,4) in [-1,1] with transparent pixels at -1, indexed batches are (source_idx,
+target_idx, palette) int32.  The random streams (shuffle order, augmentation draws) are numpy's, not TensorFlow's."""
 import itertools
+import os
 
 import numpy as np
 
-from .configuration import BATCH_SIZE, IMG_SIZE, MAX_PALETTE_SIZE, SEED, INVALID_INDEX_COLOR
+from .configuration import (BATCH_SIZE, DATA_FOLDERS, DIRECTION_FOLDERS, IMG_SIZE, INVALID_INDEX_COLOR, MAX_PALETTE_SIZE, SEED,
+                            TEST_SIZES, TRAIN_SIZES)
 
 
 class Dataset:
@@ -37,7 +47,7 @@ class Dataset:
         def gen():
             for batch in self._make_iter():
                 for i in range(len(batch[0])):
-                    yield tuple(np.asarray(t)[i] for t in batch)
+                    yield tuple(_item(t, i) for t in batch)
         return Dataset(gen)
 
     def batch(self, n):
@@ -47,11 +57,26 @@ class Dataset:
                 chunk = list(itertools.islice(it, n))
                 if not chunk:
                     return
-                yield tuple(np.stack([c[k] for c in chunk]) for k in range(len(chunk[0])))
+                yield tuple(_stack([c[k] for c in chunk]) for k in range(len(chunk[0])))
         return Dataset(gen)
 
     def as_numpy_iterator(self):
         return self._make_iter()
+
+
+def _is_torch(t):
+    return type(t).__module__.startswith("torch")
+
+
+def _item(t, i):
+    return t[i] if _is_torch(t) else np.asarray(t)[i]
+
+
+def _stack(items):
+    if _is_torch(items[0]):
+        import torch
+        return torch.stack(items)
+    return np.stack(items)
 
 
 def _sprite(rng, size, palette, pixels_transparent=0.835):
@@ -125,3 +150,164 @@ def synthetic_indexed_batch(rng, batch, img_size, palette_size=24):
     pal[:, :palette_size, 3] = 255
     pal[:, 0] = 0
     return draw(), draw(), pal
+
+
+# ---- the sprite pipeline (dataset_utils.py:66-246) ---------------------------------------------------------------------------
+AUGMENT_PROBABILITY = 0.8                      # create_augmentation_with_prob(0.8), dataset_utils.py:219
+HUE_MAX_DELTA = 0.5                            # tf.image.stateless_random_hue(image_rgb, 0.5, seed), :82
+TRANSLATE_HEIGHT = (-0.15, 0.075)              # RandomTranslation((-0.15, 0.075), 0.125, ...), :89
+TRANSLATE_WIDTH = (-0.125, 0.125)
+
+
+def sprite_paths(direction, sizes, split, data_folders=None, root="."):
+    """files of one direction in image-number order: image k of the concatenated datasets is file `<k - offset>.png` of the
+    dataset it falls in (the tf.while_loop of dataset_utils.py:158-166,184-192)"""
+    out = []
+    for folder, n in zip(data_folders or DATA_FOLDERS, sizes):
+        out += [os.path.join(root, folder, split, DIRECTION_FOLDERS[direction], f"{i}.png") for i in range(n)]
+    return out
+
+
+def load_sprites(paths, img_size=IMG_SIZE):
+    """uint8 (n, S, S, 4), as tf.image.decode_png(channels=4) + reshape (dataset_utils.py:67-69)"""
+    from . import png
+    out = np.empty((len(paths), img_size, img_size, 4), np.uint8)
+    for k, p in enumerate(paths):
+        img = png.read_png(p)
+        if img.shape != (img_size, img_size, 4):
+            raise ValueError(f"{p}: expected a {img_size}x{img_size} sprite, got {img.shape[:2]}")
+        out[k] = img
+    return out
+
+
+def blacken_transparent_pixels(image):
+    """dataset_utils.py:11-20 (host form, used at load time by the indexed pipeline): colour of alpha == 0 pixels -> 0"""
+    image = np.array(image)
+    image[image[..., 3] == 0] = 0
+    return image
+
+
+class SpriteRGBADataset(Dataset):
+    """load_rgba_ds's train or test dataset: range(n).shuffle(n) [reshuffled every iteration] -> load pair -> augment with
+    probability 0.8 (train, augment=True) -> normalise -> batch(batch_size) without drop_remainder."""
+
+    def __init__(self, source_sprites, target_sprites, augment, batch_size=BATCH_SIZE, seed=SEED, device=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device or "cuda:0")
+        self.n, self.S = len(source_sprites), source_sprites.shape[1]
+        both = np.concatenate([source_sprites, target_sprites], axis=0)
+        self.sprites = torch.from_numpy(both).to(self.device)            # uint8 [2n][S][S][4], resident
+        self.augment, self.batch_size, self.seed = augment, batch_size, seed
+        self.epoch = 0
+        super().__init__(self._iterate)
+
+    def batch_parameters(self, rng, picks):
+        """host-side draws of one batch: (int32 [2][B] sprite numbers, f32 [B][4] augmentation rows or None)"""
+        B = len(picks)
+        idx = np.stack([picks, picks + self.n]).astype(np.int32)
+        if not self.augment:
+            return idx, None
+        aug = np.zeros((B, 4), np.float32)
+        aug[:, 0] = rng.random(B) < AUGMENT_PROBABILITY
+        aug[:, 1] = rng.uniform(-HUE_MAX_DELTA, HUE_MAX_DELTA, B)
+        aug[:, 2] = rng.uniform(*TRANSLATE_HEIGHT, B) * self.S
+        aug[:, 3] = rng.uniform(*TRANSLATE_WIDTH, B) * self.S
+        return idx, aug
+
+    def make_batch(self, idx, aug):
+        """one kernel launch: (source, target) f32 (B,S,S,4) device tensors"""
+        import ctypes as C
+        from . import _lib as L
+        torch = self.torch
+        B = idx.shape[1]
+        idx_d = torch.from_numpy(idx).to(self.device, non_blocking=True)
+        aug_d = torch.from_numpy(aug).to(self.device, non_blocking=True) if aug is not None else None
+        src = torch.empty((B, self.S, self.S, 4), dtype=torch.float32, device=self.device)
+        tgt = torch.empty_like(src)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.call("p2p_sprites_rgba_batch", C.c_void_p(self.sprites.data_ptr()), 2 * self.n, self.S, C.c_void_p(idx_d[0].data_ptr()),
+               C.c_void_p(idx_d[1].data_ptr()), C.c_void_p(aug_d.data_ptr()) if aug_d is not None else None, B, 1,
+               C.c_void_p(src.data_ptr()), C.c_void_p(tgt.data_ptr()), st)
+        return src, tgt
+
+    def _iterate(self):
+        rng = np.random.default_rng([self.seed, self.epoch])
+        self.epoch += 1
+        order = rng.permutation(self.n)
+        for i in range(0, self.n, self.batch_size):
+            idx, aug = self.batch_parameters(rng, order[i:i + self.batch_size])
+            yield self.make_batch(idx, aug)
+
+
+class SpriteIndexedDataset(Dataset):
+    """load_indexed_ds's train or test dataset (dataset_utils.py:123-164,232-246).  Nothing on this path is random per step,
+    so the union palette of every pair and both index maps are extracted once here (io_utils.py) and live in HBM as int32
+    tables; a batch is three row gathers."""
+
+    def __init__(self, source_sprites, target_sprites, palette_ordering, batch_size=BATCH_SIZE, seed=SEED, device=None):
+        import torch
+        from . import io_utils
+        self.torch = torch
+        self.device = torch.device(device or "cuda:0")
+        self.n, self.S = len(source_sprites), source_sprites.shape[1]
+        rng = np.random.default_rng([seed, 7])
+        src_idx = np.empty((self.n, self.S, self.S, 1), np.int32)
+        tgt_idx = np.empty_like(src_idx)
+        pal = np.empty((self.n, MAX_PALETTE_SIZE, 4), np.int32)
+        for k in range(self.n):
+            s = blacken_transparent_pixels(source_sprites[k]).astype(np.int32)
+            t = blacken_transparent_pixels(target_sprites[k]).astype(np.int32)
+            pal[k] = io_utils.extract_palette(np.concatenate([s, t], axis=-1), palette_ordering, rng=rng)
+            src_idx[k] = io_utils.rgba_to_indexed(s, pal[k])
+            tgt_idx[k] = io_utils.rgba_to_indexed(t, pal[k])
+        self.tables = [torch.from_numpy(a.reshape(self.n, -1)).to(self.device) for a in (src_idx, tgt_idx, pal)]
+        self.shapes = [(self.S, self.S, 1), (self.S, self.S, 1), (MAX_PALETTE_SIZE, 4)]
+        self.batch_size, self.seed, self.epoch = batch_size, seed, 0
+        super().__init__(self._iterate)
+
+    def make_batch(self, picks):
+        import ctypes as C
+        from . import _lib as L
+        torch = self.torch
+        B = len(picks)
+        sel = torch.from_numpy(np.asarray(picks, np.int32)).to(self.device, non_blocking=True)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        out = []
+        for table, shape in zip(self.tables, self.shapes):
+            o = torch.empty((B,) + shape, dtype=torch.int32, device=self.device)
+            L.call("p2p_gather_rows_i32", C.c_void_p(table.data_ptr()), self.n, table.shape[1], C.c_void_p(sel.data_ptr()), B,
+                   C.c_void_p(o.data_ptr()), st)
+            out.append(o)
+        return tuple(out)
+
+    def _iterate(self):
+        rng = np.random.default_rng([self.seed, self.epoch])
+        self.epoch += 1
+        order = rng.permutation(self.n)
+        for i in range(0, self.n, self.batch_size):
+            yield self.make_batch(order[i:i + self.batch_size])
+
+
+def _pair_sprites(source_direction, target_direction, split, sizes, data_folders, root):
+    return (load_sprites(sprite_paths(source_direction, sizes, split, data_folders, root)),
+            load_sprites(sprite_paths(target_direction, sizes, split, data_folders, root)))
+
+
+def load_rgba_ds(source_direction, target_direction, augment=True, *, batch_size=BATCH_SIZE, data_folders=None, root=".",
+                 train_sizes=None, test_sizes=None, seed=SEED, device=None):
+    """dataset_utils.py:209-229 -> (train_dataset, test_dataset); keyword arguments are this build's (the reference reads the
+    same values from configuration.py)."""
+    tr = _pair_sprites(source_direction, target_direction, "train", train_sizes or TRAIN_SIZES, data_folders, root)
+    te = _pair_sprites(source_direction, target_direction, "test", test_sizes or TEST_SIZES, data_folders, root)
+    return (SpriteRGBADataset(*tr, augment=augment, batch_size=batch_size, seed=seed, device=device),
+            SpriteRGBADataset(*te, augment=False, batch_size=batch_size, seed=seed + 1, device=device))
+
+
+def load_indexed_ds(source_direction, target_direction, palette_ordering, *, batch_size=BATCH_SIZE, data_folders=None, root=".",
+                    train_sizes=None, test_sizes=None, seed=SEED, device=None):
+    """dataset_utils.py:232-246 -> (train_dataset, test_dataset) of (source_idx, target_idx, palette) batches"""
+    tr = _pair_sprites(source_direction, target_direction, "train", train_sizes or TRAIN_SIZES, data_folders, root)
+    te = _pair_sprites(source_direction, target_direction, "test", test_sizes or TEST_SIZES, data_folders, root)
+    return (SpriteIndexedDataset(*tr, palette_ordering=palette_ordering, batch_size=batch_size, seed=seed, device=device),
+            SpriteIndexedDataset(*te, palette_ordering=palette_ordering, batch_size=batch_size, seed=seed + 1, device=device))

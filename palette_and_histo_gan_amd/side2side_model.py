@@ -206,12 +206,13 @@ class S2SModel(ABC):
         real, fake = [], []
         for batch in dataset.unbatch().take(num_images).batch(1):
             out = self.generate(batch)
+            host = lambda t: (t.detach().cpu() if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t)))   # noqa: E731
             if len(batch) == 3:          # (source_idx, target_idx, palette)
-                pal = torch.as_tensor(np.asarray(batch[2][0]))
-                real.append(io_utils.indexed_to_rgba(torch.as_tensor(np.asarray(batch[1][0])), pal).to(torch.float32))
+                pal = host(batch[2][0])
+                real.append(io_utils.indexed_to_rgba(host(batch[1][0]), pal).to(torch.float32))
                 fake.append(io_utils.indexed_to_rgba(out[0].cpu(), pal).to(torch.float32))
             else:
-                real.append(torch.as_tensor(np.asarray(batch[1][0]), dtype=torch.float32))
+                real.append(host(batch[1][0]).to(torch.float32))
                 fake.append(out[0].to(torch.float32).cpu())
         return torch.stack(real), torch.stack(fake)
 

@@ -1,0 +1,104 @@
+"""-m gpu: the sprite batch kernels (csrc/sprites.hip) against the oracle's restatement of the reference pipeline
+(oracle/input_pipeline.py), and the two loaders driven end to end through the model classes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import input_pipeline as ip
+from palette_and_histo_gan_amd import _lib as L
+from palette_and_histo_gan_amd import dataset_utils as D
+from palette_and_histo_gan_amd import pix2pix_model as M
+from tests import sprite_fixtures as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _f32_normalise(u8):
+    return u8.astype(np.float32) / np.float32(127.5) - np.float32(1.0)
+
+
+def test_rgba_batch_kernel_equals_the_oracle(tmp_path):
+    data = F.write_dataset(str(tmp_path), 9, 2, directions=(0, 2))
+    ds = D.SpriteRGBADataset(data[("train", 0)], data[("train", 2)], augment=True, batch_size=16, seed=1, device=DEV)
+    rng = np.random.default_rng(4)
+    picks = rng.integers(0, 9, size=16)
+    idx, aug = ds.batch_parameters(rng, picks)
+    aug[0] = [1, 0.0, 0.0, 0.0]                    # augmentation on, identity parameters
+    aug[1] = [1, 0.25, 3.0, -2.0]                  # integer shift
+    aug[2] = [1, -0.5, 0.5, -0.5]                  # the rounding ties
+    aug[3] = [0, 0.3, 5.0, 5.0]                    # not applied: parameters must be ignored
+    aug[4] = [1, 0.5, -9.6, 8.0]                   # the extremes of the ranges
+    src, tgt = ds.make_batch(idx, aug)
+    torch.cuda.synchronize()
+    src, tgt = src.cpu().numpy(), tgt.cpu().numpy()
+    for b in range(16):
+        ws, wt = ip.make_pair(data[("train", 0)][picks[b]], data[("train", 2)][picks[b]], aug[b])
+        for got, want in ((src[b], ws), (tgt[b], wt)):
+            assert got.shape == (64, 64, 4) and got.min() >= -1.0 - 1e-6 and got.max() <= 1.0 + 1e-6
+            # hue rotation in f32 on 0..255 values: a few ulp of 255, i.e. ~1e-6 after x/127.5 - 1
+            assert np.abs(got - want).max() < 2e-5, (b, np.abs(got - want).max())
+    # rows without augmentation are pure gather + blacken + normalise: bit-exact against the f32 formula
+    for b in (3,):
+        want = _f32_normalise(D.blacken_transparent_pixels(data[("train", 0)][picks[b]]))
+        assert np.array_equal(src[b], want)
+    # aug = NULL (test set)
+    src2, tgt2 = ds.make_batch(idx, None)
+    for b in range(16):
+        assert np.array_equal(src2[b].cpu().numpy(), _f32_normalise(D.blacken_transparent_pixels(data[("train", 0)][picks[b]])))
+        assert np.array_equal(tgt2[b].cpu().numpy(), _f32_normalise(D.blacken_transparent_pixels(data[("train", 2)][picks[b]])))
+
+
+def test_bad_arguments_fail_loudly():
+    t = torch.zeros(64, device=DEV)
+    with pytest.raises(RuntimeError):
+        L.call("p2p_sprites_rgba_batch", C.c_void_p(t.data_ptr()), 1, 48, C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None, 1, 1,
+               C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None)
+    with pytest.raises(RuntimeError):
+        L.call("p2p_gather_rows_i32", C.c_void_p(t.data_ptr()), 1, 6, C.c_void_p(t.data_ptr()), 1, C.c_void_p(t.data_ptr()), None)
+
+
+def test_load_rgba_ds_end_to_end(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    data = F.write_dataset(str(tmp_path), 10, 5, directions=(2, 3))
+    train, test = D.load_rgba_ds(2, 3, augment=True, batch_size=4, train_sizes=[10], test_sizes=[5], device=DEV)
+    batches = list(train)
+    assert [len(b[0]) for b in batches] == [4, 4, 2]               # batch() keeps the ragged tail (dataset_utils.py:223)
+    assert all(b[0].is_cuda and b[0].dtype == torch.float32 and tuple(b[0].shape[1:]) == (64, 64, 4) for b in batches)
+    again = list(D.load_rgba_ds(2, 3, augment=True, batch_size=4, train_sizes=[10], test_sizes=[5], device=DEV)[0])
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(batches, again))     # same seed, same stream
+    second_epoch = list(train)
+    assert not all(torch.equal(a[0], b[0]) for a, b in zip(batches, second_epoch))                       # reshuffled
+    # the test set is the un-augmented sprites, every one exactly once per pass
+    seen = torch.cat([b[1] for b in test]).cpu().numpy()
+    want = np.stack([_f32_normalise(D.blacken_transparent_pixels(s)) for s in data[("test", 3)]])
+    assert seen.shape == want.shape
+    assert sorted(map(bytes, seen)) == sorted(map(bytes, want))
+    # transparent pixels arrive as -1 in all four channels
+    alpha0 = seen[..., 3] == -1.0
+    assert alpha0.any() and (seen[alpha0] == -1.0).all()
+    # and the model classes consume these datasets like the notebook does (experiments.ipynb cells 3-4)
+    model = M.Pix2PixModel(train, test, "front2right", "pix2pix-sprites", lambda_l1=100.0)
+    model.fit(3, 2, callbacks=["evaluate_l1"])
+    assert model.engine.G.t == 3
+
+
+def test_load_indexed_ds_end_to_end(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    F.write_dataset(str(tmp_path), 6, 3, directions=(0, 1))
+    train, test = D.load_indexed_ds(0, 1, "grayness", batch_size=4, train_sizes=[6], test_sizes=[3], device=DEV)
+    host = [t.cpu() for t in train.tables]
+    seen = 0
+    for src, tgt, pal in train:
+        assert src.dtype == torch.int32 and tuple(src.shape[1:]) == (64, 64, 1) and tuple(pal.shape[1:]) == (256, 4)
+        for b in range(len(src)):
+            k = [i for i in range(6) if torch.equal(host[2][i].reshape(256, 4), pal[b].cpu())]
+            assert k and any(torch.equal(host[0][i].reshape(64, 64, 1), src[b].cpu()) and
+                             torch.equal(host[1][i].reshape(64, 64, 1), tgt[b].cpu()) for i in k)
+        seen += len(src)
+    assert seen == 6
+    model = M.Pix2PixIndexedModel(train, test, "back2left", "pix2pix-indexed-sprites", lambda_segmentation=0.5)
+    model.fit(2, 2, callbacks=["evaluate_l1"])
+    assert model.engine.G.t == 2
