@@ -12,7 +12,7 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = ["igemm_kernel", "wgemm_kernel", "wgrad_small_kernel", "conv_strip_kernel", "conv_fewin_kernel", "conv_fewout_kernel",
+FAMILIES = ["brig_kernel", "igemm_kernel", "wgemm_kernel", "wgrad_small_kernel", "conv_strip_kernel", "conv_fewin_kernel", "conv_fewout_kernel",
             "norm_act_fwd_vec", "norm_act_bwd_vec", "norm_act_fwd_small", "norm_act_bwd_small", "adam_flat_dev_kernel",
             "weight_prep_batched_kernel", "act_bwd_vec_kernel", "pack_pair_kernel", "ws_slab_sum_kernel", "rgbuv_hist_fwd_kernel",
             "rgbuv_hist_bwd_kernel", "softmax256_kernel"]
@@ -40,13 +40,15 @@ def main():
                       "SQ_WAIT_INST_LDS"):
                 if k in c:
                     r["frac_" + k] = round(c[k] / wc, 4)
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            r["lds_conflict_per_active"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
         if c.get("SQ_BUSY_CYCLES"):
             r["mfma_busy_per_sq_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / c["SQ_BUSY_CYCLES"], 4)
         res[fam] = r
     json.dump({"source": "rocprofv3 --pmc (SQ block, one pass) of bench.py --config c2; quad-cycle units for SQ_WAVE_CYCLES / "
                          "SQ_WAIT_* / SQ_ACTIVE_INST_*", "kernels": res}, open(out, "w"), indent=1)
     for fam, r in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
-        print(fam, {k: v for k, v in r.items() if k.startswith("frac_") or k.startswith("mfma") or k == "launches"})
+        print(fam, {k: v for k, v in r.items() if k.startswith("frac_") or k.startswith("mfma") or k.startswith("lds_") or k == "launches"})
 
 
 if __name__ == "__main__":
