@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import reference_graph as rg                       # noqa: E402
 from palette_and_histo_gan_amd import _lib as L               # noqa: E402
