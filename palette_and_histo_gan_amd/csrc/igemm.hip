@@ -44,6 +44,9 @@ struct IgemmArgs {
                          // centre taps of the 2x2 input, op P: the one tap per sub-pixel phase); the others only ever
                          // multiply the zero halo
     int act; float alpha;
+    int w_major;         // logical block order: 0 = column tile fastest (an XCD owns a range of pixel tiles and reads ALL weights),
+                         // 1 = pixel tile fastest (an XCD owns a range of (column tile, phase, K split) and reads all pixels but
+                         // only its share of the weights): taken when the weights are the larger operand (deep layers)
     // fused InstanceNorm statistics (VEPI epilogue): per (image, slot, channel) the mean and the centred sum of squares
     // of `stat_rows` consecutive output pixels of one image; slot = phase * tiles_per_image + tile_in_image
     float* stat_part; int stat_rows; int stat_slots; int lgHW;
@@ -82,7 +85,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
     // pixels (all output-channel tiles, all 4 sub-pixel phases) sit next to each other and share an XCD's L2
     const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
     const unsigned lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
-    const int by = lin % gridDim.y, bz = (lin / gridDim.y) % gridDim.z, bx = lin / (gridDim.y * gridDim.z);
+    int bx, by, bz;
+    if (a.w_major) { bx = lin % gridDim.x; by = (lin / gridDim.x) % gridDim.y; bz = lin / (gridDim.x * gridDim.y); }
+    else { by = lin % gridDim.y; bz = (lin / gridDim.y) % gridDim.z; bx = lin / (gridDim.y * gridDim.z); }
     const int m0 = bx * BM, n0 = by * BN;
     const int ks = bz % a.splitk, phase = bz / a.splitk;
     const int ph = phase >> 1, pw = phase & 1;
@@ -490,6 +495,15 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
     a.w = (const char*)w;
     a.M = N * LH * LW; a.LW = LW; a.LH = LH;
     a.splitk = splitk;
+    {   // every XCD has its own L2: whichever operand an XCD's blocks share is fetched once per XCD, the other 8 times
+        // (r02 PMC: the deep layers fetched 89 MB per launch for 8-17 MB of weights).  Give the XCDs shares of the LARGER one.
+        static int wm = -1;
+        if (wm < 0) { const char* e = getenv("P2P_IGEMM_WMAJOR"); wm = e ? atoi(e) : 1; }
+        const int in_pix_per_lo = a.mode == 0 ? stride * stride : 1;
+        const long long a_bytes = (long long)N * LH * LW * in_pix_per_lo * C * esz;
+        const long long w_bytes = (long long)(a.live_taps ? 4 : 16) * ncols * C * esz;
+        a.w_major = (wm && w_bytes > a_bytes) ? 1 : 0;
+    }
     const int phases = a.mode == 1 ? 4 : 1;
     hipStream_t st = (hipStream_t)stream;
     // vector epilogue: whole 16-byte chunks of each pixel's channel run must be addressable

@@ -269,6 +269,7 @@ class Pix2PixEngine:
         self.use_conv_fewout = os.environ.get("P2P_CONV_FEWOUT", "1") != "0"    # 1..4-output heads: tap-major GEMM + shifted sum
         self.use_conv_strip = os.environ.get("P2P_CONV_STRIP", "1") != "0"      # up6 (32 <-> 128 channels): LDS strip, weights in registers
         self.use_conv_fewin = os.environ.get("P2P_CONV_FEWIN", "1") != "0"      # 8-channel inputs: weights in registers, strip in LDS
+        self.wgemm_want = int(os.environ.get("P2P_WGEMM_WANT", "512"))     # workgroups wanted per 128x128-tile weight-gradient GEMM
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self._prep_table = None
         self.refresh_weight_copies()
@@ -465,7 +466,7 @@ class Pix2PixEngine:
         nw = (bg // 32) * (bd // 32)
         nw = 4 if nw >= 4 else nw
         tiles = 16 * ((cg + bg - 1) // bg) * ((cd + bd - 1) // bd)
-        want = 512 if nw == 4 else 4096 // nw
+        want = self.wgemm_want if nw == 4 else 4096 // nw
         min_chunk = 256 if nw == 4 else 1024
         m = B * lh * lh
         ms = 1
