@@ -211,11 +211,6 @@ class Pix2PixModel(S2SModel):
         test_examples = self.test_ds.unbatch().take(num_test_examples).batch(1)
         return list(test_examples.as_numpy_iterator()) + list(train_examples.as_numpy_iterator())
 
-    def preview_generated_images_during_training(self, examples, save_name, step):
-        """The reference plots input/target/generated triples (pix2pix_model.py:112-125); here the images are generated
-        (so the forward path runs exactly as in the reference's loop) and returned, plotting is out of scope."""
-        return [self.generate(ex) for ex in examples]
-
     def evaluate_l1_batch(self, batch):
         source, target = batch[0], batch[1]
         fake = self.generate((source, target))
@@ -294,6 +289,17 @@ class Pix2PixIndexedModel(Pix2PixModel):
         """pix2pix_model.py:283-287"""
         source_image = batch[0]
         return self.engine.generate_indexed(source_image)
+
+    def debug_discriminator_patches(self, batch_of_one):
+        """pix2pix_model.py:372-431: as the base class, on index images (the discriminator of this model sees indices)"""
+        source, real = batch_of_one[0], batch_of_one[1]
+        fake = self.generate(batch_of_one)
+        out = {}
+        for name, img in (("real", real), ("fake", fake)):
+            logits = self.discriminator([img, source], training=True)
+            prob = torch.sigmoid(logits[0, :, :, 0].to(torch.float32)).cpu().numpy()
+            out[name], out[name + "_mean"] = prob, float(prob.mean())
+        return out
 
     def generate_with_probs(self, batch):
         """pix2pix_model.py:289-293"""

@@ -1,4 +1,5 @@
-"""PNG -> uint8 RGBA array, the part of tf.image.decode_png(image, channels=4) that the sprite loader needs
+"""PNG <-> uint8 RGBA array: the part of tf.image.decode_png(image, channels=4) that the sprite loader needs, and a writer
+for the preview sheets (the reference saves matplotlib figures, pix2pix_model.py:112-150).  Decoder:
 (dataset_utils.py:66-69): 8-bit, non-interlaced images of colour type 0/2/3/4/6.  Chunk parsing and zlib inflate are Python
 standard library; the scanline un-filtering (Paeth & co., sequential per byte) is the host function p2p_png_unfilter of the
 C-ABI library -- no PIL/libpng dependency."""
@@ -66,6 +67,31 @@ def decode_png(data):
             alpha[:len(trns)] = trns[:len(plte)]
         rgba[..., :3], rgba[..., 3] = plte[px[..., 0]], alpha[px[..., 0]]
     return rgba
+
+
+def encode_png(rgba):
+    """uint8 array (H, W, 4) -> bytes of an 8-bit RGBA PNG (scanline filter "Up", which suits sprites and previews)"""
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    if rgba.ndim != 3 or rgba.shape[2] != 4:
+        raise ValueError("encode_png takes an (H, W, 4) uint8 array")
+    h, w, _ = rgba.shape
+    rows = rgba.reshape(h, w * 4)
+    up = np.zeros_like(rows)
+    up[1:] = rows[:-1]
+    filt = np.empty((h, 1 + w * 4), np.uint8)
+    filt[:, 0] = 2
+    filt[:, 1:] = rows - up            # uint8 arithmetic wraps modulo 256, as the filter is defined
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    return (_SIGNATURE + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(filt.tobytes(), 6)) + chunk(b"IEND", b""))
+
+
+def write_png(path, rgba):
+    with open(path, "wb") as f:
+        f.write(encode_png(rgba))
+    return path
 
 
 def read_png(path):

@@ -175,7 +175,7 @@ class S2SModel(ABC):
                 step_start_time = time.time()
                 self.preview_generated_images_during_training(examples, None, step + 1)
                 if "show_discriminator_output" in callbacks:
-                    print("Discriminator output patches: plotting is not part of this build (skipped)")
+                    self.show_discriminated_images("test", 2)          # side2side_model.py:96-97 (numbers instead of plots)
                 if "evaluate_l1" in callbacks:
                     l1_train, l1_test = self.report_l1(step=(step + 1) // update_steps)
                     print(f" L1: {float(l1_train):.5f} / {float(l1_test):.5f} (train/test)")
@@ -194,9 +194,72 @@ class S2SModel(ABC):
     def select_examples_for_visualization(self, number_of_examples=6):
         pass
 
-    @abstractmethod
+    def _to_rgba_u8(self, image, palette=None):
+        """one (S,S,C) image of a batch as displayable uint8 RGBA: normalised RGBA -> (x * 0.5 + 0.5) * 255 (what the reference
+        hands to imshow, pix2pix_model.py:141), palette indices -> palette colours (io_utils.py:96-103)"""
+        from . import io_utils
+        t = image.detach().cpu() if isinstance(image, torch.Tensor) else torch.as_tensor(np.asarray(image))
+        if palette is not None:
+            pal = palette.detach().cpu() if isinstance(palette, torch.Tensor) else torch.as_tensor(np.asarray(palette))
+            return io_utils.indexed_to_rgba(t.to(torch.int64), pal).clamp(0, 255).to(torch.uint8).numpy()
+        return ((t.to(torch.float32) * 0.5 + 0.5).clamp(0, 1) * 255.0).round().to(torch.uint8).numpy()
+
     def preview_generated_images_during_training(self, examples, save_name, step):
-        pass
+        """pix2pix_model.py:127-157 / :332-365: one row per example with the columns Input | Target | Generated.  The
+        reference draws a matplotlib figure; here the sheet is a uint8 RGBA array (returned) and, with `save_name`, a PNG."""
+        from . import png
+        rows = []
+        for ex in examples:
+            fake = self.generate(ex)
+            pal = ex[2][0] if len(ex) == 3 else None
+            tiles = [self._to_rgba_u8(ex[0][0], pal), self._to_rgba_u8(ex[1][0], pal), self._to_rgba_u8(fake[0], pal)]
+            gap = np.zeros((tiles[0].shape[0], 2, 4), np.uint8)
+            rows.append(np.concatenate([tiles[0], gap, tiles[1], gap, tiles[2]], axis=1))
+            rows.append(np.zeros((2, rows[-1].shape[1], 4), np.uint8))
+        sheet = np.concatenate(rows[:-1], axis=0) if rows else np.zeros((1, 1, 4), np.uint8)
+        if save_name is not None:
+            folder = os.path.dirname(save_name)
+            if folder:
+                os.makedirs(folder, exist_ok=True)
+            png.write_png(save_name, sheet)
+        return sheet
+
+    def generate_images_from_dataset(self, dataset_name="test", num_images=None, steps=None):
+        """side2side_model.py:202-224: `<TEMP_FOLDER>/generated-images/<architecture>/<model>/<i>.png`, one sheet per sample"""
+        import shutil
+        from .configuration import TRAIN_SIZE
+        is_test = dataset_name == "test"
+        limit = TEST_SIZE if is_test else TRAIN_SIZE
+        num_images = limit if num_images is None else min(num_images, limit)
+        dataset = list((self.test_ds if is_test else self.train_ds).unbatch().take(num_images).batch(1).as_numpy_iterator())
+        base = os.sep.join([TEMP_FOLDER, "generated-images", self.architecture_name, self.model_name])
+        shutil.rmtree(base, ignore_errors=True)
+        os.makedirs(base, exist_ok=True)
+        for i, images in enumerate(dataset):
+            self.preview_generated_images_during_training([images], os.sep.join([base, f"{i}.png"]), steps)
+        print(f"Generated {len(dataset)} images (using \"{dataset_name}\" dataset)")
+        return base
+
+    def debug_discriminator_patches(self, batch_of_one):
+        """pix2pix_model.py:160-231: sigmoid of the discriminator's patch logits for the real and the generated image of one
+        sample (the reference plots them); returns {"real": (h,w) array, "fake": ..., "real_mean": float, "fake_mean": float}"""
+        source, real = batch_of_one[0], batch_of_one[1]
+        fake = self.generator(source, training=True)
+        out = {}
+        for name, img in (("real", real), ("fake", fake)):
+            logits = self.discriminator([img, source], training=True)
+            prob = torch.sigmoid(logits[0, :, :, 0].to(torch.float32)).cpu().numpy()
+            out[name], out[name + "_mean"] = prob, float(prob.mean())
+        return out
+
+    def show_discriminated_images(self, dataset_name="test", num_images=2):
+        """side2side_model.py:228-239 (numbers instead of plots)"""
+        dataset = self.test_ds if dataset_name == "test" else self.train_ds
+        res = []
+        for images in list(dataset.unbatch().take(num_images).batch(1).as_numpy_iterator()):
+            res.append(self.debug_discriminator_patches(images))
+            print(f"Discriminated target {res[-1]['real_mean']:.3f} / generated {res[-1]['fake_mean']:.3f}")
+        return res
 
     # -- evaluation (side2side_model.py:140-176) ---------------------------------------------------------------------------
     def select_examples_for_evaluation(self, num_images, dataset):

@@ -17,6 +17,7 @@ def test_png_decoder_all_filter_types_and_errors(tmp_path):
     img = rng.integers(0, 256, size=(16, 12, 4), dtype=np.uint8)
     for filters in [(0,), (1,), (2,), (3,), (4,), (0, 1, 2, 3, 4), (4, 3, 2, 1)]:
         assert (png.decode_png(F.encode_png(img, filters)) == img).all()
+    assert (png.decode_png(png.encode_png(img)) == img).all()          # the product's own writer (preview sheets)
     with pytest.raises(ValueError):
         png.decode_png(b"not a png at all")
     bad = bytearray(F.encode_png(img))

@@ -47,6 +47,18 @@ def test_fit_loop_runs_like_the_notebook(tmp_path, monkeypatch):
     assert tuple(fake.shape) == (4, 64, 64, 4) and float(fake.abs().max()) <= 1.0
     logits = model.discriminator([next(iter(test))[1], next(iter(test))[0]], training=True)
     assert tuple(logits.shape) == (4, 32, 32, 1)
+    # the notebook's evaluation calls (side2side_model.py:202-239): sheets Input | Target | Generated as PNG files
+    from palette_and_histo_gan_amd import png
+    folder = model.generate_images_from_dataset("test", num_images=3)
+    files = sorted(os.listdir(folder))
+    assert files == ["0.png", "1.png", "2.png"]
+    sheet = png.read_png(os.path.join(folder, "1.png"))
+    assert sheet.shape == (64, 3 * 64 + 4, 4)
+    first = next(iter(test.unbatch().take(2).batch(1)))                       # sample 0 of the test set
+    want = np.round((np.asarray(first[0][0], np.float32) * 0.5 + 0.5) * 255).astype(np.uint8)
+    assert (png.read_png(os.path.join(folder, "0.png"))[:, :64] == want).all()
+    patches = model.show_discriminated_images("test", 2)
+    assert len(patches) == 2 and patches[0]["real"].shape == (32, 32) and 0.0 < patches[0]["fake_mean"] < 1.0
 
 
 def test_scalar_log_does_not_synchronise_and_hooks_fail_loudly(tmp_path, monkeypatch):
