@@ -294,10 +294,18 @@ def _pair_sprites(source_direction, target_direction, split, sizes, data_folders
             load_sprites(sprite_paths(target_direction, sizes, split, data_folders, root)))
 
 
+def _default_seed(seed):
+    if seed is not None:
+        return seed
+    from .tf_compat import global_seed          # tf.random.set_seed(SEED) of the notebook (experiments.ipynb cell 3)
+    return global_seed()
+
+
 def load_rgba_ds(source_direction, target_direction, augment=True, *, batch_size=BATCH_SIZE, data_folders=None, root=".",
-                 train_sizes=None, test_sizes=None, seed=SEED, device=None):
+                 train_sizes=None, test_sizes=None, seed=None, device=None):
     """dataset_utils.py:209-229 -> (train_dataset, test_dataset); keyword arguments are this build's (the reference reads the
     same values from configuration.py)."""
+    seed = _default_seed(seed)
     tr = _pair_sprites(source_direction, target_direction, "train", train_sizes or TRAIN_SIZES, data_folders, root)
     te = _pair_sprites(source_direction, target_direction, "test", test_sizes or TEST_SIZES, data_folders, root)
     return (SpriteRGBADataset(*tr, augment=augment, batch_size=batch_size, seed=seed, device=device),
@@ -305,8 +313,9 @@ def load_rgba_ds(source_direction, target_direction, augment=True, *, batch_size
 
 
 def load_indexed_ds(source_direction, target_direction, palette_ordering, *, batch_size=BATCH_SIZE, data_folders=None, root=".",
-                    train_sizes=None, test_sizes=None, seed=SEED, device=None):
+                    train_sizes=None, test_sizes=None, seed=None, device=None):
     """dataset_utils.py:232-246 -> (train_dataset, test_dataset) of (source_idx, target_idx, palette) batches"""
+    seed = _default_seed(seed)
     tr = _pair_sprites(source_direction, target_direction, "train", train_sizes or TRAIN_SIZES, data_folders, root)
     te = _pair_sprites(source_direction, target_direction, "test", test_sizes or TEST_SIZES, data_folders, root)
     return (SpriteIndexedDataset(*tr, palette_ordering=palette_ordering, batch_size=batch_size, seed=seed, device=device),

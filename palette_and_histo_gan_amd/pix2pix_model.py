@@ -74,8 +74,11 @@ class Adam:
 
 class Pix2PixModel(S2SModel):
     def __init__(self, train_ds, test_ds, model_name, architecture_name, lambda_l1, dtype="bf16", img_size=IMG_SIZE,
-                 device="cuda:0", data_parallel=None, seed=47):
+                 device="cuda:0", data_parallel=None, seed=None):
         super().__init__(train_ds, test_ds, model_name, architecture_name)
+        if seed is None:
+            from .tf_compat import global_seed      # configuration.SEED unless the notebook's tf.random.set_seed changed it
+            seed = global_seed()
         self.lambda_l1 = lambda_l1
         self._dtype = {"bf16": L.BF16, "f32": L.F32}[dtype] if isinstance(dtype, str) else dtype
         self._img_size, self._device, self._seed = img_size, device, seed

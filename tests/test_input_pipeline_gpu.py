@@ -1,6 +1,7 @@
 """-m gpu: the sprite batch kernels (csrc/sprites.hip) against the oracle's restatement of the reference pipeline
 (oracle/input_pipeline.py), and the two loaders driven end to end through the model classes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -102,3 +103,17 @@ def test_load_indexed_ds_end_to_end(tmp_path, monkeypatch):
     model = M.Pix2PixIndexedModel(train, test, "back2left", "pix2pix-indexed-sprites", lambda_segmentation=0.5)
     model.fit(2, 2, callbacks=["evaluate_l1"])
     assert model.engine.G.t == 2
+
+
+def test_notebook_script_runs_end_to_end(tmp_path):
+    """examples/experiments.py = experiments.ipynb with the imports changed: every model kind trains, evaluates, saves"""
+    import subprocess
+    import sys
+    F.write_dataset(str(tmp_path), 6, 3, directions=(2, 3))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for kind in (1, 2, 3):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "experiments.py"), "--model", str(kind), "--epochs", "2",
+                            "--train-size", "6", "--test-size", "3"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "L1:" in r.stdout and "Generated 3 images" in r.stdout
+    assert os.path.exists(tmp_path / "models" / "py" / "generator" / "front-to-right" / "histogram" / "weights.p2pw.npz")
