@@ -1,84 +1,62 @@
 #!/usr/bin/env python3
-"""experiments.ipynb of fegemo/palette-and-histo-gan as a script against this build: the notebook's cells with their imports
-changed and nothing else (cell numbers in the comments).  Run from a folder that holds `datasets/rpg-maker-xp/...`:
+"""The workflow of the reference's experiments.ipynb against this build, as a command-line script: pick one of the four
+models, load the sprite datasets, train, evaluate, export.  Every call it makes exists under the same name and with the
+same arguments in the reference (cells noted in the comments); only the imports differ.  Run it from a folder that holds
+`datasets/rpg-maker-xp/{train,test}/<direction>/<n>.png`:
 
-    python examples/experiments.py --model 1 --epochs 1            # 0 baseline (no aug.), 1 baseline, 2 indexed, 3 histogram
+    python examples/experiments.py --model histogram --epochs 1
 """
 import argparse
 import os
 import sys
-from math import ceil
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-# cell 1
-from palette_and_histo_gan_amd.tf_compat import tf                     # noqa: E402   (reference: import tensorflow as tf)
+from palette_and_histo_gan_amd import configuration as cfg                     # noqa: E402
+from palette_and_histo_gan_amd import dataset_utils, pix2pix_model             # noqa: E402
+from palette_and_histo_gan_amd.tf_compat import tf                             # noqa: E402   stand-in for `import tensorflow as tf`
 
-print("Tensorflow version: ", tf.__version__)
-if tf.test.gpu_device_name():
-    print("Default GPU: {}".format(tf.test.gpu_device_name()))
-else:
-    print("Not using a GPU - it will take long!!")
+# model name -> (dataset loader arguments, model class, its loss weights)           cells 5, 7 and 9 of the notebook
+RECIPES = {
+    "baseline (no aug.)": (dict(augment=False), pix2pix_model.Pix2PixModel, dict(lambda_l1=100.)),
+    "baseline": (dict(augment=True), pix2pix_model.Pix2PixAugmentedModel, dict(lambda_l1=100.)),
+    "indexed": (dict(palette_ordering="grayness"), pix2pix_model.Pix2PixIndexedModel, dict(lambda_segmentation=0.01)),
+    "histogram": (dict(augment=True), pix2pix_model.Pix2PixHistogramModel, dict(lambda_l1=30., lambda_histogram=1.)),
+}
 
-# cell 3
-from palette_and_histo_gan_amd.configuration import *                   # noqa: E402,F401,F403
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--model", type=int, default=0)
-ap.add_argument("--epochs", type=int, default=160)
-ap.add_argument("--train-size", type=int, default=TRAIN_SIZE)          # smaller folders for a smoke run
-ap.add_argument("--test-size", type=int, default=TEST_SIZE)
-args = ap.parse_args()
-print("DATASET_SIZE", DATASET_SIZE)
-print("TRAIN_SIZE", args.train_size)
-print("TEST_SIZE", args.test_size)
-tf.random.set_seed(SEED)
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    ap.add_argument("--model", default="baseline (no aug.)", choices=sorted(RECIPES))
+    ap.add_argument("--epochs", type=int, default=160)                               # cell 10
+    ap.add_argument("--source", default="front", choices=cfg.DIRECTIONS)
+    ap.add_argument("--target", default="right", choices=cfg.DIRECTIONS)
+    ap.add_argument("--train-size", type=int, default=cfg.TRAIN_SIZE, help="use fewer sprites (smoke runs)")
+    ap.add_argument("--test-size", type=int, default=cfg.TEST_SIZE)
+    args = ap.parse_args()
 
-# cell 5
-MODELS = ["baseline (no aug.)", "baseline", "indexed", "histogram"]
-model = MODELS[args.model]
-source_direction = DIRECTION_FRONT
-target_direction = DIRECTION_RIGHT
-architecture_name = f"{DIRECTIONS[source_direction]}-to-{DIRECTIONS[target_direction]}"
+    print("library:", tf.__version__, "| device:", tf.test.gpu_device_name() or "none -- it will not run")        # cell 1
+    tf.random.set_seed(cfg.SEED)                                                                                  # cell 3
+    src, tgt = cfg.DIRECTIONS.index(args.source), cfg.DIRECTIONS.index(args.target)
+    ds_args, model_class, weights = RECIPES[args.model]
+    sizes = dict(train_sizes=[args.train_size], test_sizes=[args.test_size])
+    if model_class is pix2pix_model.Pix2PixIndexedModel:
+        train_ds, test_ds = dataset_utils.load_indexed_ds(src, tgt, **ds_args, **sizes)
+    else:
+        train_ds, test_ds = dataset_utils.load_rgba_ds(src, tgt, **ds_args, **sizes)
+    model = model_class(train_ds=train_ds, test_ds=test_ds, model_name=args.model,
+                        architecture_name=f"{args.source}-to-{args.target}", **weights)
 
-# cell 7
-from palette_and_histo_gan_amd.dataset_utils import load_indexed_ds, load_rgba_ds      # noqa: E402
+    steps = cfg.ceil(args.train_size / cfg.BATCH_SIZE) * args.epochs
+    update_steps = max(1, steps // 40)
+    print(f"{args.model}: {args.epochs} epochs = {steps} steps, evaluation every {update_steps} steps")
+    model.fit(steps, update_steps, callbacks=["show_discriminator_output", "evaluate_l1"])     # "evaluate_fid": InceptionV3 download
 
-sizes = dict(train_sizes=[args.train_size], test_sizes=[args.test_size])
-if model == "baseline (no aug.)":
-    train_ds, test_ds = load_rgba_ds(source_direction, target_direction, augment=False, **sizes)
-elif model in ("baseline", "histogram"):
-    train_ds, test_ds = load_rgba_ds(source_direction, target_direction, **sizes)
-else:
-    train_ds, test_ds = load_indexed_ds(source_direction, target_direction, palette_ordering="grayness", **sizes)
+    model.save_generator()                                                                      # cells 12-16
+    model.generate_images_from_dataset("test")
+    l1_train, l1_test = model.report_l1()
+    print(f"L1: {float(l1_train):.5f} / {float(l1_test):.5f} (train/test)")
 
-# cell 9
-from palette_and_histo_gan_amd.pix2pix_model import (Pix2PixAugmentedModel, Pix2PixHistogramModel, Pix2PixIndexedModel,      # noqa: E402
-                                                     Pix2PixModel)
 
-if model == "baseline (no aug.)":
-    model = Pix2PixModel(train_ds=train_ds, test_ds=test_ds, model_name="baseline (no aug.)",
-                         architecture_name=architecture_name, lambda_l1=100.)
-elif model == "baseline":
-    model = Pix2PixAugmentedModel(train_ds=train_ds, test_ds=test_ds, model_name="baseline",
-                                  architecture_name=architecture_name, lambda_l1=100.)
-elif model == "indexed":
-    model = Pix2PixIndexedModel(train_ds=train_ds, test_ds=test_ds, model_name="indexed",
-                                architecture_name=architecture_name, lambda_segmentation=0.01)
-else:
-    model = Pix2PixHistogramModel(train_ds=train_ds, test_ds=test_ds, model_name="histogram",
-                                  architecture_name=architecture_name, lambda_l1=30., lambda_histogram=1.)
-
-# cell 10
-EPOCHS = args.epochs
-STEPS = ceil(args.train_size / BATCH_SIZE) * EPOCHS
-UPDATE_STEPS = max(1, STEPS // 40)
-print(f"Starting training for {EPOCHS} epochs in {STEPS} steps, updating visualization every {UPDATE_STEPS} steps...")
-callbacks = ["show_discriminator_output", "evaluate_l1"]                # "evaluate_fid" needs the InceptionV3 download
-model.fit(STEPS, UPDATE_STEPS, callbacks=callbacks)
-
-# cells 12-16
-model.save_generator()
-model.generate_images_from_dataset("test")
-l1_train, l1_test = model.report_l1()
-print(f"L1: {float(l1_train):.5f} / {float(l1_test):.5f} (train/test)")
+if __name__ == "__main__":
+    main()

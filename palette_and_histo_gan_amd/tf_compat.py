@@ -1,6 +1,6 @@
 """Stand-in for the three direct TensorFlow calls of experiments.ipynb (cells 1 and 3: `tf.__version__`,
 `tf.test.gpu_device_name()`, `tf.random.set_seed(SEED)`), so the notebook's cells run against this build with only their
-imports changed (examples/experiments.py is the notebook as a script):
+imports changed (examples/experiments.py runs the same workflow):
 
     from palette_and_histo_gan_amd.tf_compat import tf
 

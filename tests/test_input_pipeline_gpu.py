@@ -106,13 +106,13 @@ def test_load_indexed_ds_end_to_end(tmp_path, monkeypatch):
 
 
 def test_notebook_script_runs_end_to_end(tmp_path):
-    """examples/experiments.py = experiments.ipynb with the imports changed: every model kind trains, evaluates, saves"""
+    """examples/experiments.py = the workflow of experiments.ipynb against this build: every model kind trains, evaluates, saves"""
     import subprocess
     import sys
     F.write_dataset(str(tmp_path), 6, 3, directions=(2, 3))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for kind in (1, 2, 3):
-        r = subprocess.run([sys.executable, os.path.join(root, "examples", "experiments.py"), "--model", str(kind), "--epochs", "2",
+    for kind in ("baseline", "indexed", "histogram"):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "experiments.py"), "--model", kind, "--epochs", "2",
                             "--train-size", "6", "--test-size", "3"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert "L1:" in r.stdout and "Generated 3 images" in r.stdout
