@@ -31,7 +31,8 @@
 #include <utility>
 
 // Diagnostic builds only (tools/ubench/build_abl.sh): 1 = DMA and barriers without LDS reads / MFMAs, 2 = LDS reads + MFMAs
-// without DMA, 3 = everything but never wait for the DMA (stale operands), 4 / 5 = as 1 with the input blocks / the weights only
+// without DMA, 3 = everything but never wait for the DMA (stale operands), 4 / 5 = as 1 with the input blocks / the weights only,
+// 6 / 7 = everything (MFMAs included) but without the weight / input-block DMA
 #ifndef P2P_ABL
 #define P2P_ABL 0
 #endif
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
     // tap slab of (phase | plane) pq for tap index tt = 2a + b: kh = 1 - p + 2a, kw = 1 - q + 2b
     auto widx = [](int pq, int tt) { return ((1 - (pq >> 1)) + 2 * (tt >> 1)) * 4 + (1 - (pq & 1)) + 2 * (tt & 1); };
     auto issue_w = [&](int step) {          // stage of global step `step` (clamped past the end: lands in a free slot, never read)
-        if (P2P_ABL == 4) return;
+        if (P2P_ABL == 4 || P2P_ABL == 6) return;
         const int total = a.nkc * NT;
         if (step >= total) step = total - 1;
         const int kc = step / NT, t = step - kc * NT;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         }
     };
     auto issue_a = [&](int kc, int i) {     // piece i of this wave for K chunk kc
-        if (P2P_ABL == 5) return;
+        if (P2P_ABL == 5 || P2P_ABL == 7) return;
         if (kc >= a.nkc) kc = a.nkc - 1;
         long long off;
         if (MODE == 1) off = (long long)kc * CK * esz;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         const int pq = MODE == 1 ? quarter : (kc & 3);
         brig_static_for(std::make_integer_sequence<int, NT>{}, [&](auto tt) {
             constexpr int t = decltype(tt)::value;
-            if (P2P_ABL != 3 && P2P_ABL < 4) brig_wait_vm<brig_vm<NT, NWST>(t)>();
+            if (P2P_ABL != 3 && (P2P_ABL < 4 || P2P_ABL >= 6)) brig_wait_vm<brig_vm<NT, NWST>(t)>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             // every wave has finished reading step s-1: its weight slot and (at t = 0) the other input buffer are free
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
             // issue their LDS-DMA (tens of cycles of issue time per instruction) while the matrix pipe idles.  The second half
             // issues its DMA after its first MFMA group instead, so one partner multiplies while the other stages.
             const bool late = stagger && half != 0;       // wave-uniform
-            if (!late || P2P_ABL == 1 || P2P_ABL >= 4) issue_dma();
-            if (P2P_ABL != 1 && P2P_ABL < 4) {
+            if (!late || P2P_ABL == 1 || P2P_ABL == 4 || P2P_ABL == 5) issue_dma();
+            if (P2P_ABL != 1 && P2P_ABL != 4 && P2P_ABL != 5) {
                 load_set(0, wfA, afA);
                 mfma_set(wfB, afB);              // last sub-step of the previous step (zeros before the first one)
                 if (late) issue_dma();
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
             }
         });
     }
-    if (P2P_ABL != 1 && P2P_ABL < 4) mfma_set(wfB, afB);
+    if (P2P_ABL != 1 && P2P_ABL != 4 && P2P_ABL != 5) mfma_set(wfB, afB);
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
