@@ -35,6 +35,7 @@ struct IgemmArgs {
     const float* bias;                                              // GEN epilogue, may be null
     int M, lgLW, lgLH, LW, LH;
     int C, lgCB, Cc;     // contraction channels per tap, log2(C*sizeof(T)) (pow2 path), 16-byte chunks per tap
+    unsigned cc_inv;     // ceil(2^24 / Cc): chunk index -> tap by one multiply (exact for every chunk index of a launch while Cc <= 1024; GEN path)
     int w_rows;          // rows of a weight tap slab (>= the launched column tiles)
     int ncols;           // real output channels (stores are masked to col < ncols)
     int mode;            // 0 = G, 1 = P stride 2 (4 phases), 2 = P stride 1
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
     auto split_k = [&](int kb, int q, int& tl, int& cbyte) {
         if (GEN) {
             int kc = kb * 8 + q;
-            int tp = kc / a.Cc;
+            int tp = (int)(((unsigned)kc * a.cc_inv) >> 24);      // kc / Cc without the ~20-instruction integer division per piece
             tl = tap_begin + tp;
             cbyte = (kc - tp * a.Cc) << 4;
         } else {
@@ -470,6 +471,8 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
     P2P_REQUIRE((in->ld * esz) % 16 == 0 && ((uintptr_t)in->ptr % 16) == 0 && ((uintptr_t)w % 16) == 0,
                 "p2p_igemm: input pixels and weights must be 16-byte aligned");
     a.Cc = C * esz / 16;
+    a.cc_inv = (unsigned)(((1u << 24) + a.Cc - 1) / a.Cc);
+    P2P_REQUIRE(a.Cc <= 1024, "p2p_igemm: more than 1024 16-byte chunks per tap (C=%d)", C);      // cc_inv is exact up to there (checked exhaustively)
     a.lgCB = ilog2_exact((long long)C * esz);
     const bool pow2 = a.lgCB >= 6 && ncols == w_rows && !bias && act == P2P_ACT_NONE;
     a.mode = op == P2P_OP_G ? 0 : (stride == 2 ? 1 : 2);
