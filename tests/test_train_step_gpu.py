@@ -44,8 +44,8 @@ def grad_report(eng_grads, ref_grads):
     return worst_max, worst_l2
 
 
-def run_case(dtype, use_mfma, seed=21):
-    B, S = 2, 64
+def run_case(dtype, use_mfma, seed=21, B=2):
+    S = 64
     rng, Gp, Dp, src, tgt, masks = setup_case(B, S, seed)
     tm = [torch.tensor(m, dtype=F64) for m in masks]
     if dtype == L.BF16:      # same graph, same bf16 storage points (oracle/reference_graph.storage_dtype)
@@ -72,6 +72,29 @@ def test_train_step_f32_mfma_matches_oracle():
     for i in (0, 1, 2, 4, 5, 6):
         assert abs(out[i] - want[i]) <= 1e-4 * abs(want[i]), (i, out[i], want[i])
     assert wg[0][1] < 1e-4 and wd[0][1] < 1e-4
+
+
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_train_step_f32_odd_batches(B):
+    """batch sizes that are not powers of two: B = 1 is what the reference's evaluation feeds (`.batch(1)`, pix2pix_model.py:107-
+    115), ragged tail batches of an epoch are 1..3 samples (dataset_utils.py:223 has no drop_remainder); tiles that hold four
+    8x8 images or two strips are then partly empty"""
+    out, want, wg, wd = run_case(L.F32, True, seed=40 + B, B=B)
+    for i in (0, 1, 2, 4, 5, 6):
+        assert abs(out[i] - want[i]) <= 1e-4 * abs(want[i]), (i, out[i], want[i])
+    # Typical worst tensor: 5e-6.  Roughly one case in four has ONE gated element (ReLU / LeakyReLU / dropout) whose
+    # pre-activation is ~1e-6 from zero and lands on the other side in f32: the f64 oracle re-run in f32 shows the very same
+    # outlier (tests/diagnostics/odd_batch_errors.py; e.g. seed 61: up4.kernel 0.198 of its max-norm, 0.009 in L2, for the
+    # oracle as for the engine), so the bound on every tensor is the L2 one and the max-norm bound holds for the D tensors
+    assert wg[1][1] < 2e-2 and wd[0][1] < 1e-4
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_train_step_bf16_odd_batches(B):
+    out, want, wg, wd = run_case(L.BF16, True, seed=50 + B, B=B)
+    for i in (0, 1, 2, 4, 5, 6):
+        assert abs(out[i] - want[i]) <= 2e-3 * abs(want[i]), (i, out[i], want[i])
+    assert wg[1][1] < 0.3 and wd[1][1] < 0.3
 
 
 def test_train_step_f32_direct_kernels_match_oracle():
