@@ -271,7 +271,9 @@ class Pix2PixEngine:
         self.use_conv_fewin = os.environ.get("P2P_CONV_FEWIN", "1") != "0"      # 8-channel inputs: weights in registers, strip in LDS
         self.wgemm_want = int(os.environ.get("P2P_WGEMM_WANT", "512"))     # workgroups wanted per 128x128-tile weight-gradient GEMM
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
-        self._prep_table = None
+        self._prep_table = {}
+        self._head_prepped = False
+        self.split_prep = int(os.environ.get("P2P_SPLIT_PREP", "1"))    # weight copies of the early-Adam part refreshed right behind it
         self.refresh_weight_copies()
 
     # ------------------------------------------------------------------ parameters
@@ -317,21 +319,26 @@ class Pix2PixEngine:
                     lw.wd = torch.zeros(16 * cg * cd, dtype=tdt, device=dev)
                 self.W[(sid, name)] = lw
 
-    def _prep_tasks(self):
+    def _prep_tasks(self, part="all"):
         """Device table of p2p_prep_task descriptors (one per weight copy set); the pointers are stable for the life
-        of the engine, so it is built once."""
-        if self._prep_table is not None:
-            return self._prep_table
+        of the engine, so it is built once.  part = "head": the generator layers whose parameters lie in front of the last
+        gradient bucket (what _adam_head updates early), "rest": the others, "all": every layer."""
+        if self._prep_table.get(part) is not None:
+            return self._prep_table[part]
+        head_end = self.G.buckets[-1][0] if len(self.G.buckets) >= 2 else 0
         specs = []
         for (sid, name), lw in self.W.items():
+            in_head = sid == "G" and self.G.offsets[name + ".kernel"] + 16 * lw.cg * lw.cd <= head_end
+            if (part == "head" and not in_head) or (part == "rest" and in_head):
+                continue
             master = self._store(sid).p(name + ".kernel")
             if lw.wt is not None or lw.wn is not None:
                 specs.append((master, lw.cg, lw.cd, lw.wn, up32(lw.cg), lw.lo_pad, lw.wt, up32(lw.cd), lw.hi_pad))
             if lw.wd is not None:
                 specs.append((master, lw.cg, lw.cd, lw.wd, lw.cg, lw.cd, None, 0, 0))
         if not specs:
-            self._prep_table = (None, 0, 0)
-            return self._prep_table
+            self._prep_table[part] = (None, 0, 0)
+            return self._prep_table[part]
         tasks = (L.PrepTask * len(specs))()
         first = 0
         for k, (master, cg, cd, wn, wn_r, wn_c, wt, wt_r, wt_c) in enumerate(specs):
@@ -346,12 +353,12 @@ class Pix2PixEngine:
             t.tiles_g, t.tiles_d, t.first_block = tg.value, td.value, first
             first += nb
         raw = torch.frombuffer(bytearray(bytes(tasks)), dtype=torch.uint8).to(self.device)
-        self._prep_table = (raw, len(specs), first)
-        return self._prep_table
+        self._prep_table[part] = (raw, len(specs), first)
+        return self._prep_table[part]
 
-    def refresh_weight_copies(self):
-        """Re-derives the per-layer weight copies from the f32 masters; runs after every Adam step (one launch)."""
-        raw, ntasks, total = self._prep_tasks()
+    def refresh_weight_copies(self, part="all"):
+        """Re-derives the per-layer weight copies from the f32 masters; runs after every Adam step (one launch per part)."""
+        raw, ntasks, total = self._prep_tasks(part)
         if ntasks:
             L.call("p2p_weight_prep_batched", self.dtype, _p(raw), ntasks, total, _stream())
 
@@ -974,6 +981,12 @@ class Pix2PixEngine:
         n = self.G.buckets[-1][0]
         L.call("p2p_adam_flat_dev", _p(self.G.params), _p(self.G.grads), _p(self.G.m), _p(self.G.v), n,
                _p(self.G.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+        if self.split_prep:
+            # their weight copies too: the data-gradient kernels that read them are done (same stream), the other stream's
+            # last weight gradients do not read weight copies -- a memory-bound launch beside MFMA-bound ones instead of
+            # alone at the step boundary
+            self.refresh_weight_copies("head")
+            self._head_prepped = True
         return n
 
     def apply_adam(self, g_from=0):
@@ -989,7 +1002,8 @@ class Pix2PixEngine:
                    store.numel - off, _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
         if not ticked:
             L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
-        self.refresh_weight_copies()
+        head_done, self._head_prepped = self._head_prepped and g_from > 0, False
+        self.refresh_weight_copies("rest" if head_done else "all")
 
     def _histogram_loss(self, P, B, Bg, lambda_hist, hist_allreduce):
         """Pix2PixHistogramModel.generator_loss (pix2pix_model.py:242-250): Hellinger(rgbuv_hist(real), rgbuv_hist(fake)).
