@@ -150,6 +150,14 @@ int p2p_conv_fewin(int op, int stride, int dtype, int N, int LH, int LW, int cin
                    const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias,
                    int act, float alpha, void* stream);
 
+/* p2p_conv_fewin followed by the backward of the LeakyReLU in front of the layer, in one launch: out = conv(in) * (gate > 0 ?
+ * 1 : alpha) with `gate` = the activation output of that block (same shape as out; whole 16-byte channel runs).  Bit-identical
+ * to p2p_conv_fewin + p2p_act_bwd; the gradient tensor between them is never written (reference: the tape gradient through
+ * the discriminator's first block, networks.py:45-48, pix2pix_model.py:78-79). */
+int p2p_conv_fewin_actbwd(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                          const p2p_tensor* in, const p2p_tensor* out, const void* w, const p2p_tensor* gate, float alpha,
+                          void* stream);
+
 /* MFMA weight gradient of a stride-2 block: dw[16][Cg][Cd] (f32) = sum over pixels.  The pixel sum is
  * split over `msplit` workgroups per tile; partial slabs go to `workspace`
  * (p2p_wgemm_workspace_bytes) and are reduced deterministically. */

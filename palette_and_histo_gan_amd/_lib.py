@@ -34,6 +34,7 @@ SIGNATURES = {
     "p2p_igemm_edge": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_conv_strip": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp],
     "p2p_conv_fewin": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
+    "p2p_conv_fewin_actbwd": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _TP, _f, _vp],
     "p2p_conv_fewout": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_wgemm_edge": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
     "p2p_wgrad_small": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp],

@@ -18,6 +18,7 @@ struct FiArgs {
     char* out; long long out_img; int out_row; int out_ld;
     const char* w; int w_rows;                             // [16][w_rows][8] bf16
     const float* bias; int act; float alpha;
+    const char* gate; long long gate_img; int gate_row; int gate_ld;     // optional: out *= LeakyReLU'(gate) (gate > 0 ? 1 : alpha)
     int LH, LW, lgLW;
     int ncols;
     int mode, S;                                           // 0 = G (stride S), 2 = P stride 1
@@ -117,7 +118,17 @@ __global__ __launch_bounds__(256 * NT) void conv_fewin_kernel(FiArgs a) {
             const int pp = tile * 32 + pix;
             const int py = pp >> a.lgLW, px = pp & (a.LW - 1);
             if (c0 < a.ncols) {
-                const f32x4 v = *(const f32x4*)(pL + pix * PROW + ch * 16);
+                f32x4 v = *(const f32x4*)(pL + pix * PROW + ch * 16);
+                if (a.gate) {
+                    // backward of the LeakyReLU that produced `gate` (the layer's activation output), applied to the ROUNDED
+                    // gradient exactly as p2p_act_bwd would apply it to the stored tensor: the results are bit-identical to
+                    // convolution + p2p_act_bwd, without writing and re-reading the gradient (host checked ncols % 8 == 0)
+                    const bf16x8 gt = *(const bf16x8*)((const bf16_t*)a.gate + ((long long)n * a.gate_img + (long long)(y0 + py) * a.gate_row + px) * a.gate_ld + c0);
+                    bf16x8 e = *(const bf16x8*)&v;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = (bf16_t)((float)e[k] * ((float)gt[k] > 0.f ? 1.f : a.alpha));
+                    v = *(const f32x4*)&e;
+                }
                 bf16_t* op = (bf16_t*)a.out + ((long long)n * a.out_img + (long long)(y0 + py) * a.out_row + px) * a.out_ld + c0;
                 if (a.vec && c0 + 8 <= a.ncols) *(f32x4*)op = v;
                 else {
@@ -159,9 +170,9 @@ extern "C" int p2p_conv_fewin_ok(int op, int stride, int dtype, int N, int LH, i
     return fi_plan(op, stride, dtype, N, LH, LW, cin_pad, ncols).ok;
 }
 
-extern "C" int p2p_conv_fewin(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
-                              const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias, int act,
-                              float alpha, void* stream) {
+static int conv_fewin_common(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                             const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias, int act,
+                             float alpha, const p2p_tensor* gate, void* stream) {
     P2P_REQUIRE(in && out && in->ptr && out->ptr && w, "p2p_conv_fewin: null pointer");
     P2P_REQUIRE(w_rows >= 1, "p2p_conv_fewin: w_rows must be positive");
     const FiPlan p = fi_plan(op, stride, dtype, N, LH, LW, cin_pad, ncols);
@@ -173,6 +184,12 @@ extern "C" int p2p_conv_fewin(int op, int stride, int dtype, int N, int LH, int 
     a.out = (char*)out->ptr; a.out_img = out->img_stride; a.out_row = out->row_stride; a.out_ld = out->ld;
     a.w = (const char*)w; a.w_rows = w_rows;
     a.bias = bias; a.act = act; a.alpha = alpha;
+    a.gate = nullptr; a.gate_img = 0; a.gate_row = a.gate_ld = 0;
+    if (gate) {
+        P2P_REQUIRE(gate->ptr && ncols % 8 == 0 && gate->ld % 8 == 0 && ((uintptr_t)gate->ptr % 16) == 0 && out->ld % 8 == 0 &&
+                    ((uintptr_t)out->ptr % 16) == 0, "p2p_conv_fewin_actbwd: gate and output must hold whole 16-byte channel runs");
+        a.gate = (const char*)gate->ptr; a.gate_img = gate->img_stride; a.gate_row = gate->row_stride; a.gate_ld = gate->ld;
+    }
     a.LH = LH; a.LW = LW;
     a.lgLW = 0;
     while ((1 << a.lgLW) < LW) ++a.lgLW;
@@ -187,4 +204,20 @@ extern "C" int p2p_conv_fewin(int op, int stride, int dtype, int N, int LH, int 
     if (p.NT == 1) conv_fewin_kernel<1><<<grid, dim3(256), p.shm, st>>>(a);
     else conv_fewin_kernel<2><<<grid, dim3(512), p.shm, st>>>(a);
     return p2p_check_launch("p2p_conv_fewin");
+}
+
+extern "C" int p2p_conv_fewin(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                              const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias, int act,
+                              float alpha, void* stream) {
+    return conv_fewin_common(op, stride, dtype, N, LH, LW, cin_pad, ncols, w_rows, in, out, w, bias, act, alpha, nullptr, stream);
+}
+
+// The data gradient of a few-channel head followed by the backward of the LeakyReLU in front of it (networks.py:45-48: the
+// discriminator's first block; tape gradient pix2pix_model.py:78-79): out = conv(in) * (gate > 0 ? 1 : alpha), gate = that
+// block's activation output.  Same result, bit for bit, as p2p_conv_fewin followed by p2p_act_bwd.
+extern "C" int p2p_conv_fewin_actbwd(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols, int w_rows,
+                                     const p2p_tensor* in, const p2p_tensor* out, const void* w, const p2p_tensor* gate,
+                                     float alpha, void* stream) {
+    P2P_REQUIRE(gate, "p2p_conv_fewin_actbwd: null gate");
+    return conv_fewin_common(op, stride, dtype, N, LH, LW, cin_pad, ncols, w_rows, in, out, w, nullptr, P2P_ACT_NONE, alpha, gate, stream);
 }

@@ -273,6 +273,7 @@ class Pix2PixEngine:
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self._prep_table = {}
         self._head_prepped = False
+        self.fuse_act_bwd = int(os.environ.get("P2P_FUSE_ACT_BWD", "1"))   # D.last data gradient + LeakyReLU backward in one launch
         self.split_prep = int(os.environ.get("P2P_SPLIT_PREP", "1"))    # weight copies of the early-Adam part refreshed right behind it
         self.refresh_weight_copies()
 
@@ -798,14 +799,27 @@ class Pix2PixEngine:
         same (pre-update) D weights down to d(fake) in g_dcat[..., :in_ch] (pix2pix_model.py:78)."""
         S, ic, h2 = self.S, self.in_ch, self.S // 2
         self._wgrad(P, "D", "last", 2 * B, h2, P["d_act"].view(), P["dld"].view(), stride=1, dbias=self.D.g("last.bias"))
-        self._conv(P, L.OP_P, "D", "last", 2 * B, h2, P["dld"].view(), P["g_dact"].view(), stride=1)
-        self._act_bwd(2 * B, h2, 64, P["d_act"].view(), P["g_dact"].gsrc(), None, P["d_draw"].view())
+        if not self._d_last_dgrad_gated(2 * B, h2, P["dld"].view(), P["d_act"].view(), P["d_draw"].view()):
+            self._conv(P, L.OP_P, "D", "last", 2 * B, h2, P["dld"].view(), P["g_dact"].view(), stride=1)
+            self._act_bwd(2 * B, h2, 64, P["d_act"].view(), P["g_dact"].gsrc(), None, P["d_draw"].view())
         self._wgrad(P, "D", "down", 2 * B, h2, P["dcat"].view(), P["d_draw"].view())
         if P.get("skip_g_through_d"):
             return
-        self._conv(P, L.OP_P, "D", "last", B, h2, P["dlg"].view(), P["g_dact_g"].view(), stride=1)
-        self._act_bwd(B, h2, 64, P["d_act"].view(n0=B), P["g_dact_g"].gsrc(), None, P["d_draw_g"].view())
+        if not self._d_last_dgrad_gated(B, h2, P["dlg"].view(), P["d_act"].view(n0=B), P["d_draw_g"].view()):
+            self._conv(P, L.OP_P, "D", "last", B, h2, P["dlg"].view(), P["g_dact_g"].view(), stride=1)
+            self._act_bwd(B, h2, 64, P["d_act"].view(n0=B), P["g_dact_g"].gsrc(), None, P["d_draw_g"].view())
         self._conv(P, L.OP_P, "D", "down", B, h2, P["d_draw_g"].view(), P["g_dcat"].view(), ncols=ic)
+
+    def _d_last_dgrad_gated(self, N, h2, dlogits_view, act_view, out_view):
+        """d(D.last)/d(features) and the LeakyReLU backward of D.down in one launch (p2p_conv_fewin_actbwd: bit-identical to the
+        two launches, the gradient tensor between them is never written); False where the few-input kernel does not apply."""
+        lw = self.W[("D", "last")]
+        if not (self.use_mfma and self.use_conv_fewin and self.fuse_act_bwd and
+                L.lib().p2p_conv_fewin_ok(L.OP_P, 1, self.dtype, N, h2, h2, lw.lo_pad, lw.cg)):
+            return False
+        L.call("p2p_conv_fewin_actbwd", L.OP_P, 1, self.dtype, N, h2, h2, lw.lo_pad, lw.cg, up32(lw.cg), C.byref(dlogits_view),
+               C.byref(out_view), self._wn("D", "last"), C.byref(act_view), LEAKY_ALPHA, _stream())
+        return True
 
     # ------------------------------------------------------------------ train step (RGBA models)
     def train_step_rgba(self, source, real, lambda_l1, lambda_hist=None, masks=None, global_batch=None,

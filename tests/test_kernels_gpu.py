@@ -635,3 +635,40 @@ def test_wgrad_small_lds_resident(dtype, n, lh, cg, cd, stride):
     L.call("p2p_wgrad_small", dtype, stride, n, lh, lh, cg, cd, C.byref(hi_b.view()), C.byref(lo_b.view()), U.ptr(dw), U.ptr(ws),
            U.stream())
     assert U.rel_err(dw.cpu().numpy().reshape(4, 4, cg, cd), w_ref) < 2e-5
+
+
+def test_conv_fewin_actbwd_equals_conv_then_act_bwd():
+    """d(D.last)/d(features) with the LeakyReLU backward of D.down fused into its epilogue (p2p_conv_fewin_actbwd) against the
+    two launches it replaces (p2p_conv_fewin, p2p_act_bwd): bit for bit, into a channel-sliced haloed output view"""
+    dtype, n, lh, cg, cd = L.BF16, 3, 32, 64, 1
+    rng = np.random.default_rng(23)
+    lo = rng.normal(size=(n, lh, lh, cd)).astype(np.float32)
+    w = (0.05 * rng.normal(size=(16, cg, cd))).astype(np.float32)
+    gate = rng.normal(size=(n, lh, lh, cg)).astype(np.float32)
+    lo_pad = E.pad8(cd)
+    lo_b = _pad_view_input(lo, lo_pad, dtype)
+    wn = torch.zeros(16 * E.up32(cg) * lo_pad, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.zeros(16 * E.up32(cd) * E.pad8(cg), dtype=U.tdt(dtype), device=U.DEV)
+    L.call("p2p_weight_prep_pad", dtype, U.ptr(U.dev(w.reshape(-1))), cg, cd, U.ptr(wn), E.up32(cg), lo_pad, U.ptr(wt), E.up32(cd),
+           E.pad8(cg), U.stream())
+    assert L.lib().p2p_conv_fewin_ok(L.OP_P, 1, dtype, n, lh, lh, lo_pad, cg)
+    gate_b = U.halo_from(gate, dtype)
+    g_mid = E.HaloBuf(n, lh, lh, cg, dtype, U.DEV)
+    two = E.HaloBuf(n, lh, lh, cg + 8, dtype, U.DEV)
+    one = E.HaloBuf(n, lh, lh, cg + 8, dtype, U.DEV)
+    L.call("p2p_conv_fewin", L.OP_P, 1, dtype, n, lh, lh, lo_pad, cg, E.up32(cg), C.byref(lo_b.view()), C.byref(g_mid.view()),
+           U.ptr(wn), None, L.ACT_NONE, 0.0, U.stream())
+    gs = L.GSrc(g_mid.view().ptr, 1, 1, 0, cg, 0)
+    # the gradient source indexes dense pixels: use a dense copy of the haloed intermediate
+    dense = g_mid.t[:, E.HALO:E.HALO + lh, E.HALO:E.HALO + lh, :].contiguous()
+    gs = L.GSrc(dense.data_ptr(), 1, 1, 0, cg, 0)
+    L.call("p2p_act_bwd", dtype, n, lh, lh, cg, C.byref(gate_b.view()), C.byref(gs), None, 0.3, C.byref(two.view(coff=8)), U.stream())
+    L.call("p2p_conv_fewin_actbwd", L.OP_P, 1, dtype, n, lh, lh, lo_pad, cg, E.up32(cg), C.byref(lo_b.view()),
+           C.byref(one.view(coff=8)), U.ptr(wn), C.byref(gate_b.view()), 0.3, U.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(one.t, two.t)
+    assert float(one.t.float().abs().max()) > 0 and np.count_nonzero(U.halo_to_np(one)[..., :8]) == 0
+    with pytest.raises(RuntimeError):      # a gate view that does not hold whole 16-byte channel runs is refused
+        bad = L.Tensor(gate_b.view().ptr, gate_b.view().img_stride, gate_b.view().row_stride, 60)
+        L.call("p2p_conv_fewin_actbwd", L.OP_P, 1, dtype, n, lh, lh, lo_pad, cg, E.up32(cg), C.byref(lo_b.view()),
+               C.byref(one.view(coff=8)), U.ptr(wn), C.byref(bad), 0.3, U.stream())
