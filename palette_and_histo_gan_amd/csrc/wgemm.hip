@@ -11,6 +11,7 @@
 // tile-row slots beyond the pixel's bytes re-read the pixel's first 16-byte chunk (never another pixel, never
 // past the view) and the store is masked to g < Cg, d < Cd.
 #include "p2p_common.hpp"
+#include <stdlib.h>
 
 struct WgemmArgs {
     const char* hi; long long hi_img; int hi_row; int hi_ld;
@@ -245,7 +246,10 @@ static int wgemm_launch(WgemmArgs& a, int msplit, hipStream_t st) {
     a.chunk = ((a.M + msplit - 1) / msplit + BK - 1) / BK * BK;
     const int cg = a.Cg, cd = a.Cd;
     if (cd > 64) {
-        if (cg > 64) wgemm_go<T, 128, 128, 2, 2, 2, 2>(a, msplit, st);
+        static int w8 = -1;
+        if (w8 < 0) { const char* e = getenv("P2P_WGEMM_W8"); w8 = e ? atoi(e) : 1; }     // eight waves (32x64 each) per 128x128 tile: -6.5 % on the kernel (r02 A/B), as in p2p_igemm
+        if (cg > 64 && w8) wgemm_go<T, 128, 128, 4, 2, 1, 2>(a, msplit, st);
+        else if (cg > 64) wgemm_go<T, 128, 128, 2, 2, 2, 2>(a, msplit, st);
         else if (cg > 32) wgemm_go<T, 64, 128, 2, 2, 1, 2>(a, msplit, st);
         else wgemm_go<T, 32, 128, 1, 4, 1, 1>(a, msplit, st);
     } else if (cd > 32) {
