@@ -89,7 +89,7 @@ def kernel_profile(eng, run_step, n_steps=3):
         orig(name, *args)
         b.record()
         # the fused block (convolution + InstanceNorm + activation) is the same kernel family as p2p_igemm, which dispatches to it
-        records.append(("p2p_igemm" if name == "p2p_igemm_norm_act" else name, args[:8], a, b))
+        records.append(("p2p_igemm" if name == "p2p_igemm_norm_act" else name, args, a, b))
 
     L.call = timed
     E.L.call = timed
@@ -216,7 +216,9 @@ def main():
                 return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B)
             prof, records = kernel_profile(eng, run_step_local)
             result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
-            result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype, MFMA_PEAK[args.dtype])
+            result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype)
+            # every entry point that matters, each against the roofline that bounds it (bf16 / exact-f32 MFMA peak, or HBM)
+            result["rooflines"] = FL.rooflines_top(prof, records, args.dtype, k=10)
             # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; reduced by
             # tools/pmc_traffic.py from separate --pmc runs of this same command and committed under profiles/).  The profile is
             # stamped with a fingerprint of the kernel sources + engine: a profile taken from other code is NOT quoted.
@@ -233,7 +235,7 @@ def main():
                     result["roofline"]["traffic_unit"] = "bytes/launch (PMC)"
                     result["roofline"]["traffic_launches_profiled"] = k.get("launches_fetch_pass")
             if args.detail:
-                FL.write_detail(records, args.detail, n_steps=3)
+                FL.write_detail(records, args.detail, n_steps=3, dtype=args.dtype)
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
             result["cpu_baseline"] = cpu_baseline("baseline" if indexed else model, S, 100.0 if indexed else lam_l1, lam_hist)
         print(json.dumps(result), flush=True)

@@ -86,7 +86,8 @@ __global__ void conv_direct_P(int stride, int N, int LH, int LW, int Cg, int Cd,
     ((T*)hi.ptr)[hi.off(n, Y, X) + g] = from_f32<T>(acc);
 }
 
-// ---- op W: dw[t][g][d] += sum over a chunk of pixels; grid.y = pixel chunks, atomics into dw ---------
+// ---- op W: dw[t][g][d] = sum over ALL pixels in pixel order, one thread per output (cross-check path: slow at large
+// batches, bit-reproducible, no float atomics) -----------------------------------------------------------------------
 template <typename T>
 __global__ void conv_direct_W(int stride, int N, int LH, int LW, int Cg, int Cd, TView hi, TView lo,
                               float* __restrict__ dw, int chunk) {
@@ -110,11 +111,11 @@ __global__ void conv_direct_W(int stride, int N, int LH, int LW, int Cg, int Cd,
         if (ih < 0 || ih >= HH || iw < 0 || iw >= HW) continue;
         acc += to_f32(((const T*)hi.ptr)[hi.off(n, ih, iw) + g]) * to_f32(((const T*)lo.ptr)[lo.off(n, y, x) + d]);
     }
-    atomicAdd(dw + idx, acc);
+    dw[idx] = acc;
 }
 
-// dbias[d] += sum over a chunk of pixels of lo[m][d]: threads = (pixel lane) x (channel), coalesced over channels,
-// pixel lanes folded through LDS, one atomic per channel per workgroup
+// sum over a chunk of pixels of lo[m][d]: threads = (pixel lane) x (channel), coalesced over channels, pixel lanes folded
+// through LDS; each workgroup writes its partial row (`part`), or -- launched as ONE workgroup over all pixels -- the sum itself
 template <typename T>
 __global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ out, int chunk, float* __restrict__ part = nullptr) {
     __shared__ float red[256];
@@ -141,13 +142,13 @@ __global__ void view_colsum(int N, int LH, int LW, int Cd, TView lo, float* __re
             float s2 = 0.f;
             for (int i = 0; i < PL; ++i) s2 += red[i * cpt + c];
             if (part) part[(long long)blockIdx.x * Cd + c0 + c] = s2;        // deterministic form: colsum_partials_kernel adds the workgroups in order
-            else atomicAdd(out + c0 + c, s2);                              // direct (non-MFMA) cross-check path only
+            else out[c0 + c] = s2;                                         // single-workgroup launch (direct cross-check path)
         }
     }
 }
 
 // Wide-channel form (Cd % 8 == 0, 16-byte aligned view): 16-byte loads, thread = (8-channel vector, pixel lane), a
-// workgroup covers `chunk` pixels; partial sums are combined through LDS and leave as one atomic per channel and workgroup.
+// workgroup covers `chunk` pixels; partial sums are combined through LDS and leave as one partial row per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void view_colsum_vec(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ part, int chunk) {
     constexpr int VN = 16 / sizeof(T);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void view_colsum_vec(int N, int LH, int LW, in
 }
 
 // Narrow form (8-channel pixels, Cd <= 8: the bias gradients of the two heads): one whole pixel per lane and step
-// (16 / 32 bytes), 8 running sums per lane, one LDS tree and one atomic per channel and workgroup.
+// (16 / 32 bytes), 8 running sums per lane, one LDS tree and one partial row per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void view_colsum_px8(int N, int LH, int LW, int Cd, TView lo, float* __restrict__ part, int chunk) {
     __shared__ float red[8][256];
@@ -274,17 +275,10 @@ static int conv_direct_impl(int op, int stride, int N, int LH, int LW, int Cg, i
     } else {
         long long M = (long long)N * LH * LW;
         int total = 16 * Cg * Cd;
-        int chunk = 512;
-        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)total, st);
-        if (e != hipSuccess) { p2p_set_error("memset dw: %s", hipGetErrorString(e)); return (int)e; }
-        dim3 grid((total + TB - 1) / TB, (unsigned)((M + chunk - 1) / chunk));
-        conv_direct_W<T><<<grid, TB, 0, st>>>(stride, N, LH, LW, Cg, Cd, hi, lo, dw, chunk);
-        if (dbias) {
-            e = hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cd, st);
-            if (e != hipSuccess) { p2p_set_error("memset dbias: %s", hipGetErrorString(e)); return (int)e; }
-            int c2 = 4096;
-            view_colsum<T><<<dim3((unsigned)((M + c2 - 1) / c2)), TB, 0, st>>>(N, LH, LW, Cd, lo, dbias, c2);
-        }
+        P2P_REQUIRE(M < (1LL << 31), "p2p_conv_direct: too many pixels");
+        dim3 grid((total + TB - 1) / TB, 1);
+        conv_direct_W<T><<<grid, TB, 0, st>>>(stride, N, LH, LW, Cg, Cd, hi, lo, dw, (int)M);
+        if (dbias) view_colsum<T><<<dim3(1), TB, 0, st>>>(N, LH, LW, Cd, lo, dbias, (int)M);
     }
     return p2p_check_launch("p2p_conv_direct");
 }

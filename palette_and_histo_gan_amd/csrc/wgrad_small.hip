@@ -355,6 +355,14 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     int TH = 512 / LW;
     if (TH > 8) TH = 8;
     if (TH > LH) TH = LH;
+    // few-channel (packed) layers: the contraction is a handful of MFMAs per strip, the kernel is a stream of strips.  One
+    // workgroup per CU alternates "stage, wait, contract" and leaves HBM idle most of the time; several co-resident workgroups
+    // (their strips are 53-71 KB, their partial slabs 4-32 KB) keep loads in flight while one of them contracts.
+    static int th_pack = -1, want_pack = -1, dbuf_pack = -1;
+    if (th_pack < 0) { const char* e = getenv("P2P_WS_TH_PACK"); th_pack = e ? atoi(e) : 8; }
+    if (want_pack < 0) { const char* e = getenv("P2P_WS_WANT_PACK"); want_pack = e ? atoi(e) : 512; }
+    if (dbuf_pack < 0) { const char* e = getenv("P2P_WS_DBUF_PACK"); dbuf_pack = e ? atoi(e) : 0; }
+    if (p.pack && TH > th_pack) TH = th_pack;
     int th1 = 0, th2 = 0;       // tallest strip with one / two buffers
     for (int t = TH; t >= 1; t >>= 1) {
         if (LH % t) continue;
@@ -363,6 +371,7 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     }
     if (!th1) return p;
     p.nbuf = (dbuf && th2 && (th2 >= 2 || th1 < 4)) ? 2 : 1;
+    if (p.pack && dbuf_pack && th2 == th1) p.nbuf = 2;
     TH = p.nbuf == 2 ? th2 : th1;
     p.buf_bytes = (int)bytes_for(TH);
     p.lo_off = (int)hi_bytes_for(TH);
@@ -372,7 +381,7 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     // workgroups wanted per launch: one per CU -- half the partial slabs of 512, c2 step 1 % faster (r02)
     static int want_env = -1;
     if (want_env < 0) { const char* e = getenv("P2P_WS_WANT"); want_env = e ? atoi(e) : 256; }
-    long long want = want_env / (p.gwins * p.dwins);
+    long long want = (p.pack ? want_pack : want_env) / (p.gwins * p.dwins);
     const long long slab_bytes = 16LL * Cg * Cd * 4;
     const long long cap = (64LL << 20) / slab_bytes;         // keep the partial slabs within 64 MB
     if (want > cap) want = cap;

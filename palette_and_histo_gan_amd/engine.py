@@ -1151,6 +1151,7 @@ class Pix2PixEngine:
         P = self.plan(B)
         S = self.S
         src_t = self._to_device(source_idx, 1, B, is_int=True)
+        self._batch_offset = 0          # evaluation: the dropout stream of sample k does not depend on the last train shard
         self._pack_source(P, src_t)
         self.generator_forward(P, masks)
         fake_view = P["dcat"].view(coff=0, n0=B)
@@ -1212,6 +1213,7 @@ class Pix2PixEngine:
         P = self.plan(B)
         S = self.S
         src_t = self._to_device(source, self.in_ch, B)
+        self._batch_offset = 0          # evaluation: the dropout stream of sample k does not depend on the last train shard
         self._pack_source(P, src_t)
         self.generator_forward(P, masks)
         fake_view = P["dcat"].view(coff=0, n0=B)

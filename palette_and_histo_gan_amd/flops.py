@@ -1,7 +1,7 @@
 """Algorithmic work of the train step: what bench.py prices the kernels against."""
 from .engine import DOWN_FILTERS, UP_FILTERS
 
-__all__ = ["layer_macs", "train_step_flops_per_image", "roofline_for_dominant"]
+__all__ = ["layer_macs", "train_step_flops_per_image", "call_work", "entry_roofline", "roofline_for_dominant", "rooflines_top"]
 
 
 def layer_macs(S, in_ch, out_ch):
@@ -35,74 +35,194 @@ def train_step_flops_per_image(S, in_ch=4, out_ch=4, indexed=False):
     return 2 * total
 
 
-def _call_flops(name, args):
-    """Algorithmic FLOPs of one C-ABI conv call from its leading integer arguments."""
-    if name == "p2p_igemm":
-        _, _, n, lh, lw, cg, cd = args[:7]
-    elif name == "p2p_wgemm":
-        _, n, lh, lw, cg, cd = args[:6]
-    elif name == "p2p_conv_direct":
-        _, _, _, n, lh, lw, cg, cd = args[:8]
-    else:
-        return None
-    return 2.0 * n * lh * lw * 16 * cg * cd
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md chip-level parameters (spec; 6.3 TB/s measured copy)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
-def roofline_for_dominant(prof, records, B, S, dtype, peak_tflops):
-    """Roofline object for the entry point that takes the most device time per step.  For the conv entry
-    points the bound is the MFMA peak and `achieved` = sum of algorithmic FLOPs of its launches / sum of their
-    event-measured durations; `traffic` (HBM bytes from PMC counters) is filled from profiles/ by hand, not here."""
-    dominant = max(prof.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
-    fl, ms, n = 0.0, 0.0, 0
-    for name, args, a, b in records:
-        if name != dominant:
+def _ints(args, n):
+    return [int(a) for a in args[:n]]
+
+
+def _view_ld(byref_obj, default):
+    """channel count of a pixel of a p2p_tensor passed with ctypes.byref"""
+    t = getattr(byref_obj, "_obj", None)
+    return int(getattr(t, "ld", default)) if t is not None else default
+
+
+def _gsrc_bytes(byref_obj, elems, esz):
+    """bytes read from a gradient source: activation-dtype tensor (kind 1) or `nslabs` f32 split-K slabs (kind 2)"""
+    g = getattr(byref_obj, "_obj", None)
+    if g is None:
+        return 0.0
+    return elems * (esz if int(g.kind) == 1 else 4 * int(g.nslabs))
+
+
+def call_work(name, args, dtype):
+    """Algorithmic work of ONE C-ABI call from its arguments (include/p2pgan.h): dict with
+         flops      multiply-add work (2 x MACs, SURVEY.md 8a / 8d D2 conventions: every tap counted, zero padding included)
+         mfma       "bf16" | "f32" | None: the matrix pipe those FLOPs run on (None: no dense contraction)
+         bytes      algorithmic HBM bytes: every operand view read once, every result written once, in the stored layout
+       or None for calls that move a few KB (loss finishing, counters)."""
+    esz = 2 if dtype == "bf16" else 4
+    mf = dtype
+    if name in ("p2p_igemm", "p2p_igemm_norm_act", "p2p_conv_strip"):
+        _, _, n, lh, lw, cg, cd = _ints(args, 7)
+        fl = 2.0 * n * lh * lw * 16 * cg * cd
+        by = (n * 4 * lh * lw * cg + n * lh * lw * cd + 16 * cg * cd) * esz
+        if name == "p2p_igemm_norm_act":          # + the normalised activation written into its concat slice
+            by += n * (lh * lw * cd if args[0] == 0 else 4 * lh * lw * cg) * esz
+        return {"flops": fl, "mfma": mf, "bytes": by}
+    if name in ("p2p_igemm_edge", "p2p_conv_fewin", "p2p_conv_fewout", "p2p_conv_fewin_actbwd"):
+        op, stride, _, n, lh, lw, cin, nc = _ints(args, 8)
+        fl = 2.0 * n * lh * lw * 16 * cin * nc
+        hi_px, lo_px = n * stride * stride * lh * lw, n * lh * lw
+        in_px, out_px = (hi_px, lo_px) if op == 0 else (lo_px, hi_px)
+        by = (in_px * cin + out_px * nc + 16 * cin * nc) * esz
+        if name == "p2p_conv_fewin_actbwd":
+            by += out_px * nc * esz                 # the forward activation that gates the gradient
+        return {"flops": fl, "mfma": mf, "bytes": by}
+    if name in ("p2p_wgemm", "p2p_wgemm_edge", "p2p_wgrad_small"):
+        if name == "p2p_wgemm":
+            _, n, lh, lw, cg, cd = _ints(args, 6)
+            stride, hi_i = 2, 6
+        else:
+            a = _ints(args, 7)
+            stride = a[1]
+            n, lh, lw, cg, cd = a[2:7]
+            hi_i = 7
+        fl = 2.0 * n * lh * lw * 16 * cg * cd
+        hi_ld, lo_ld = _view_ld(args[hi_i], cg), _view_ld(args[hi_i + 1], cd)
+        # a view that is a channel slice of a wider concat buffer is read as its own channels only
+        by = (n * stride * stride * lh * lw * min(hi_ld, max(cg, 8)) + n * lh * lw * min(lo_ld, max(cd, 8))) * esz + 16 * cg * cd * 4
+        return {"flops": fl, "mfma": mf, "bytes": by}
+    if name == "p2p_conv_direct":
+        _, _, _, n, lh, lw, cg, cd = _ints(args, 8)
+        return {"flops": 2.0 * n * lh * lw * 16 * cg * cd, "mfma": None, "bytes": 0.0}
+    if name == "p2p_norm_act_fwd":
+        _, n, h, w, c = _ints(args, 5)
+        raw_kind, nslabs = int(args[6]), int(args[7])
+        t = n * h * w * c
+        by = t * (esz if raw_kind == 1 else 4 * nslabs) + t * esz
+        if raw_kind == 2:
+            by += t * esz                           # the folded raw tensor is written for the backward pass
+        return {"flops": 0.0, "mfma": None, "bytes": by}
+    if name == "p2p_norm_act_bwd":
+        _, n, h, w, c = _ints(args, 5)
+        t = n * h * w * c
+        by = t * esz + _gsrc_bytes(args[12], t, esz) + (_gsrc_bytes(args[13], t, esz) if args[13] is not None else 0) + t * esz
+        return {"flops": 0.0, "mfma": None, "bytes": by}
+    if name == "p2p_act_bwd":
+        _, n, h, w, c = _ints(args, 5)
+        t = n * h * w * c
+        by = 2 * t * esz + _gsrc_bytes(args[6], t, esz) + (_gsrc_bytes(args[7], t, esz) if args[7] is not None else 0)
+        return {"flops": 0.0, "mfma": None, "bytes": by}
+    if name == "p2p_rgbuv_hist_fwd":
+        # histogram.py:29-30: three (64 x HW) . (HW x 64) contractions per image, exact-f32 MFMA (SURVEY.md 8d D2: 201.3 MFLOP
+        # per image PAIR at S = 64); bytes: the RGBA image in, three 64 x 64 planes out
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 3 * 2.0 * 64 * 64 * h * w * n, "mfma": "f32", "bytes": n * (h * w * 4 + 3 * 64 * 64) * 4.0}
+    if name == "p2p_rgbuv_hist_hellinger_bwd":
+        # closed-form backward (SURVEY.md 8a A11): A = GH . kv and Bm = GH^T . ku per colour component = twice the forward
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 2 * 3 * 2.0 * 64 * 64 * h * w * n, "mfma": "f32",
+                "bytes": n * (h * w * 4 + 3 * 3 * 64 * 64 + 3 * h * w * 4) * 4.0}
+    if name == "p2p_softmax_cce_argmax":
+        _, n, h, w, c = _ints(args, 5)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2.0 * c * esz + 2 * 8 * esz)}
+    if name == "p2p_adam_flat_dev":
+        return {"flops": 0.0, "mfma": None, "bytes": 7 * 4.0 * int(args[4])}        # g, m, v, p in; m, v, p out
+    if name == "p2p_adam_prep":
+        return {"flops": 0.0, "mfma": None, "bytes": (7 * 4.0 + 2 * esz) * int(args[1])}
+    if name == "p2p_pack_pair":
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2 * 4 * 4.0 + (8 + 4 + 8 + 4) * esz)}
+    if name in ("p2p_tanh_l1_fwd", "p2p_tanh_l1_bwd"):
+        _, n, h, w, c = _ints(args, 5)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * 3.0 * max(c, 8) * esz}
+    if name == "p2p_dropout_mask_dev":
+        return {"flops": 0.0, "mfma": None, "bytes": float(int(args[1]))}
+    return None
+
+
+def _call_flops(name, args, dtype="bf16"):
+    w = call_work(name, args, dtype)
+    return w["flops"] if w and w["mfma"] else None
+
+
+def entry_roofline(name, records, dtype):
+    """Roofline of one entry point over the profiled launches: the bound is whichever of (FLOPs / MFMA peak of the pipe the
+    kernel uses) and (algorithmic bytes / HBM peak) is the larger time -- an MFMA kernel is never priced against HBM unless
+    its bytes really bound it (up6's 32 <-> 128 channel block sits at the ridge)."""
+    fl = by = ms = 0.0
+    n, pipe = 0, None
+    for rname, args, a, b in records:
+        if rname != name:
             continue
-        f = _call_flops(name, args)
-        if f is None:
+        w = call_work(rname if rname != "p2p_igemm" else "p2p_igemm", args, dtype)
+        if w is None:
             continue
-        fl += f
+        fl += w["flops"] if w["mfma"] else 0.0
+        by += w["bytes"]
+        pipe = pipe or w["mfma"]
         ms += a.elapsed_time(b)
         n += 1
-    if n == 0:
-        return {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
-                "traffic": None}
-    achieved = fl / (ms * 1e-3) / 1e12
-    return {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tflops, "unit": "TFLOP/s",
-            "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": n,
-            "avg_launch_ms": round(ms / n, 5), "flops_per_launch_avg": fl / n,
-            "algorithmic_bytes_per_launch_avg": _dominant_bytes(dominant, records, dtype) / n}
+    if n == 0 or ms <= 0:
+        return None
+    t_mfma = fl / (MFMA_PEAK_TFLOPS[pipe] * 1e12) if pipe else 0.0
+    t_hbm = by / (HBM_PEAK_GBS * 1e9)
+    out = {"kernel": name, "launches": n, "avg_launch_ms": round(ms / n, 5), "flops_per_launch_avg": fl / n,
+           "algorithmic_bytes_per_launch_avg": by / n, "traffic": None}
+    if t_mfma >= t_hbm and pipe:
+        ach = fl / (ms * 1e-3) / 1e12
+        out.update({"bound": "mfma", "mfma_dtype": pipe, "achieved": round(ach, 3), "peak": MFMA_PEAK_TFLOPS[pipe],
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS[pipe], 5)})
+    else:
+        ach = by / (ms * 1e-3) / 1e9
+        out.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5)})
+    return out
 
 
-def _dominant_bytes(dominant, records, dtype):
-    """Algorithmic HBM bytes of the conv launches: input view + weights + output, each touched once."""
-    esz = 2 if dtype == "bf16" else 4
-    tot = 0.0
+def roofline_for_dominant(prof, records, B, S, dtype, peak_tflops=None):
+    """Roofline object of the entry point that takes the most device time per step."""
+    for name, _ in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+        r = entry_roofline(name, records, dtype)
+        if r is not None:
+            return r
+    return {"kernel": None, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+
+
+def rooflines_top(prof, records, dtype, k=8):
+    """the k entry points with the most device time, each with its own roofline (bench.py `rooflines`)"""
+    out = []
+    for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+        r = entry_roofline(name, records, dtype)
+        if r is not None:
+            r["ms_per_step"] = round(v["ms_per_step"], 4)
+            for key in ("traffic", "flops_per_launch_avg", "algorithmic_bytes_per_launch_avg"):
+                r.pop(key, None)
+            out.append(r)
+        if len(out) >= k:
+            break
+    return out
+
+
+def write_detail(records, path, n_steps, dtype="bf16"):
+    """Per-call table: entry point, leading integer arguments (shape), ms per launch, algorithmic TFLOP/s and GB/s."""
+    agg, work = {}, {}
     for name, args, a, b in records:
-        if name != dominant:
-            continue
-        if name == "p2p_igemm":
-            _, _, n, lh, lw, cg, cd = args[:7]
-        elif name == "p2p_wgemm":
-            _, n, lh, lw, cg, cd = args[:6]
-        else:
-            continue
-        tot += (n * 4 * lh * lw * cg + n * lh * lw * cd + 16 * cg * cd) * esz
-    return tot
-
-
-def write_detail(records, path, n_steps):
-    """Per-call table: entry point, leading integer arguments (shape), ms per launch, algorithmic TFLOP/s."""
-    agg = {}
-    for name, args, a, b in records:
-        ints = tuple(x for x in args if isinstance(x, int))
+        ints = tuple(x for x in args[:8] if isinstance(x, int))
         key = (name, ints)
+        if key not in work:
+            work[key] = call_work(name, args, dtype)
         d = agg.setdefault(key, [0.0, 0])
         d[0] += a.elapsed_time(b)
         d[1] += 1
     rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
     with open(path, "w") as f:
-        f.write("ms_per_step  launches  ms_each  TFLOP/s  entry  int-args\n")
+        f.write("ms_per_step  launches  ms_each  TFLOP/s     GB/s  entry  int-args\n")
         for (name, ints), (ms, n) in rows:
-            fl = _call_flops(name, ints)
-            tf = (fl * n / (ms * 1e-3) / 1e12) if fl else 0.0
-            f.write(f"{ms / n_steps:10.4f} {n / n_steps:8.1f} {ms / n:9.4f} {tf:8.1f}  {name} {ints}\n")
+            w = work.get((name, ints))
+            tf = (w["flops"] * n / (ms * 1e-3) / 1e12) if w and w["mfma"] else 0.0
+            gbs = (w["bytes"] * n / (ms * 1e-3) / 1e9) if w else 0.0
+            f.write(f"{ms / n_steps:10.4f} {n / n_steps:8.1f} {ms / n:9.4f} {tf:8.1f} {gbs:8.0f}  {name} {ints}\n")

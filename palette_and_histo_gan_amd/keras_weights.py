@@ -47,11 +47,23 @@ def _check(name, arr, shape):
         raise ValueError(f"{name}: shape {tuple(arr.shape)} in the file, the model expects {tuple(shape)}")
 
 
-def export_model(model, path, with_optimizer=True):
-    """Writes generator, discriminator (and both Adam states) of a Pix2Pix*Model / engine to `path` (.npz)."""
+GROUPS = ("generator", "discriminator")
+
+
+def _groups(eng, which):
+    which = GROUPS if which is None else tuple(which)
+    for tag in which:
+        if tag not in GROUPS:
+            raise ValueError(f"unknown network '{tag}' (expected a subset of {GROUPS})")
+    return [(tag, eng.G if tag == "generator" else eng.D) for tag in which]
+
+
+def export_model(model, path, with_optimizer=True, which=None):
+    """Writes the networks named in `which` (default: generator and discriminator) and, with `with_optimizer`, their Adam
+    states of a Pix2Pix*Model / engine to `path` (.npz)."""
     eng = getattr(model, "engine", model)
     out = {"format": np.array(FORMAT)}
-    for tag, store in (("generator", eng.G), ("discriminator", eng.D)):
+    for tag, store in _groups(eng, which):
         for i, (name, w) in enumerate(store.export().items()):
             out[f"{tag}/{i:03d}:{name}"] = w.astype(np.float32)
         if with_optimizer:
@@ -81,17 +93,21 @@ def _read_group(z, prefix, store):
     return vals
 
 
-def import_model(model, path, with_optimizer=True):
-    """Loads a file written by export_model (or by the reference-side snippet in the module docstring)."""
+def import_model(model, path, with_optimizer=True, which=None):
+    """Loads a file written by export_model (or by the reference-side snippet in the module docstring).  Only the networks
+    named in `which` (default: both) are touched -- their weights and, with `with_optimizer`, their Adam state; a file may
+    hold a single network as long as it holds every network asked for."""
     import torch
     eng = getattr(model, "engine", model)
     z = np.load(path, allow_pickle=False)
     if "format" in z.files and str(z["format"]) != FORMAT:
         raise ValueError(f"unknown weight file format {z['format']}")
-    for tag, store in (("generator", eng.G), ("discriminator", eng.D)):
-        vals = _read_group(z, tag, store)
+    groups = _groups(eng, which)
+    loaded = [(tag, store, _read_group(z, tag, store)) for tag, store in groups]
+    for tag, _, vals in loaded:          # validate everything before the first byte of the model changes
         if vals is None:
             raise ValueError(f"{path}: no '{tag}/NNN:name' arrays")
+    for tag, store, vals in loaded:
         store.load(vals)
         if with_optimizer and f"{tag}_optimizer/iterations" in z.files:
             store.t = int(z[f"{tag}_optimizer/iterations"])

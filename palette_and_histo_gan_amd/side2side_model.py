@@ -291,23 +291,27 @@ class S2SModel(ABC):
         """side2side_model.py:178-184: `models/py/generator/<architecture>/<model>/weights.p2pw.npz` (keras_weights.py)"""
         from . import keras_weights
         os.makedirs(self._model_path("generator"), exist_ok=True)
-        return keras_weights.export_model(self, os.path.join(self._model_path("generator"), "weights.p2pw.npz"))
+        return keras_weights.export_model(self, os.path.join(self._model_path("generator"), "weights.p2pw.npz"),
+                                          with_optimizer=False, which=("generator",))
 
     def save_discriminator(self):
         """side2side_model.py:190-196"""
         from . import keras_weights
         os.makedirs(self._model_path("discriminator"), exist_ok=True)
-        return keras_weights.export_model(self, os.path.join(self._model_path("discriminator"), "weights.p2pw.npz"))
+        return keras_weights.export_model(self, os.path.join(self._model_path("discriminator"), "weights.p2pw.npz"),
+                                          with_optimizer=False, which=("discriminator",))
 
     def load_generator(self):
-        """side2side_model.py:186-188"""
+        """side2side_model.py:186-188: replaces the generator only (the discriminator and both optimizers stay as they are)"""
         from . import keras_weights
-        keras_weights.import_model(self, os.path.join(self._model_path("generator"), "weights.p2pw.npz"))
+        keras_weights.import_model(self, os.path.join(self._model_path("generator"), "weights.p2pw.npz"),
+                                   with_optimizer=False, which=("generator",))
 
     def load_discriminator(self):
-        """side2side_model.py:198-200"""
+        """side2side_model.py:198-200: replaces the discriminator only"""
         from . import keras_weights
-        keras_weights.import_model(self, os.path.join(self._model_path("discriminator"), "weights.p2pw.npz"))
+        keras_weights.import_model(self, os.path.join(self._model_path("discriminator"), "weights.p2pw.npz"),
+                                   with_optimizer=False, which=("discriminator",))
 
     def report_l1(self, num_images=TEST_SIZE, step=None):
         """side2side_model.py:162-176"""

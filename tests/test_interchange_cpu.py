@@ -61,6 +61,36 @@ def test_keras_layout_weight_file_round_trip(tmp_path):
         KW.import_model(b, str(tmp_path / "bad.npz"))
 
 
+def test_loading_one_network_leaves_the_other_and_both_optimizers_untouched(tmp_path):
+    """side2side_model.py:186-200 replace ONE Keras model; ADVICE r02: load_generator must not clobber D or the Adam states"""
+    a, b = _HostEngine(seed=3), _HostEngine(seed=4)
+    before = {(sid, buf): getattr(st, buf).clone() for sid, st in (("G", b.G), ("D", b.D)) for buf in ("params", "m", "v")}
+    t_before = (b.G.t, b.D.t)
+    path = KW.export_model(a, str(tmp_path / "gen.p2pw.npz"), with_optimizer=False, which=("generator",))
+    z = np.load(path)
+    assert not any(k.startswith(("discriminator", "generator_optimizer")) for k in z.files)
+    KW.import_model(b, path, with_optimizer=False, which=("generator",))
+    for k in a.G.shapes:
+        assert torch.equal(a.G.view(a.G.params, k), b.G.view(b.G.params, k)), k
+    assert torch.equal(b.D.params, before[("D", "params")])
+    for sid, st in (("G", b.G), ("D", b.D)):
+        for buf in ("m", "v"):
+            assert torch.equal(getattr(st, buf), before[(sid, buf)]), (sid, buf)
+    assert (b.G.t, b.D.t) == t_before
+    # a generator-only file cannot serve a request for both networks, and nothing changes when it is refused
+    snap = b.G.params.clone()
+    with pytest.raises(ValueError):
+        KW.import_model(b, path)
+    assert torch.equal(b.G.params, snap)
+    # ... and a two-network file can serve a one-network request
+    both = KW.export_model(a, str(tmp_path / "both.p2pw.npz"))
+    KW.import_model(b, both, with_optimizer=False, which=("discriminator",))
+    assert torch.equal(a.D.view(a.D.params, "down.kernel"), b.D.view(b.D.params, "down.kernel"))
+    assert torch.equal(b.D.m, before[("D", "m")])
+    with pytest.raises(ValueError):
+        KW.import_model(b, both, which=("critic",))
+
+
 def test_palette_extraction_and_index_round_trip_are_bit_exact():
     rng = np.random.default_rng(7)
     colours = np.array([[0, 0, 0, 0], [10, 20, 30, 255], [200, 10, 10, 255], [10, 200, 10, 255], [250, 250, 250, 255],

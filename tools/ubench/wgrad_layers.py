@@ -13,8 +13,13 @@ sys.path.insert(0, ROOT)
 from palette_and_histo_gan_amd import _lib as L          # noqa: E402
 from palette_and_histo_gan_amd import engine as E        # noqa: E402
 
-B = int(os.environ.get("UB_BATCH", "256"))
-SHAPES = [("up6", 2, 32, 32, 128), ("up5", 2, 16, 64, 256), ("down2", 2, 16, 64, 128)]   # (name, stride, lh, cg, cd)
+B0 = int(os.environ.get("UB_BATCH", "256"))
+# (name, stride, lh, cg, cd, batch multiplier, hi pixel channels, lo pixel channels)
+SHAPES = [("up6", 2, 32, 32, 128, 1, 32, 128), ("up5", 2, 16, 64, 256, 1, 64, 256), ("down2", 2, 16, 64, 128, 1, 64, 128),
+          ("last", 1, 64, 36, 4, 1, 40, 8), ("D.last", 1, 32, 64, 1, 2, 64, 8), ("D.down", 2, 32, 8, 64, 2, 8, 64),
+          ("down1", 2, 32, 4, 64, 1, 8, 64)]
+if os.environ.get("UB_ONLY"):
+    SHAPES = [s for s in SHAPES if s[0] in os.environ["UB_ONLY"].split(",")]
 
 
 def main():
@@ -22,11 +27,12 @@ def main():
     dev = "cuda:0"
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device=dev).manual_seed(1)
-    for name, stride, lh, cg, cd in SHAPES:
-        hi = E.HaloBuf(B, stride * lh, stride * lh, cg, L.BF16, dev)
-        lo = E.HaloBuf(B, lh, lh, cd, L.BF16, dev)
-        for hb in (hi, lo):
-            hb.t[:, 2:-2, 2:-2, :] = torch.randn((B, hb.h, hb.w, hb.c), device=dev, generator=g).to(torch.bfloat16)
+    for name, stride, lh, cg, cd, bm, hic, loc in SHAPES:
+        B = B0 * bm
+        hi = E.HaloBuf(B, stride * lh, stride * lh, hic, L.BF16, dev)
+        lo = E.HaloBuf(B, lh, lh, loc, L.BF16, dev)
+        for hb, creal in ((hi, cg), (lo, cd)):
+            hb.t[:, 2:-2, 2:-2, :creal] = torch.randn((B, hb.h, hb.w, creal), device=dev, generator=g).to(torch.bfloat16)
         hv, lv = hi.view(), lo.view()
         nb = L.lib().p2p_wgrad_small_blocks(L.BF16, stride, B, lh, lh, cg, cd, hv.ld, lv.ld)
         ws = torch.empty(nb * 16 * cg * cd, dtype=torch.float32, device=dev)
@@ -46,7 +52,9 @@ def main():
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / reps * 1e3
         fl = 2.0 * B * lh * lh * 16 * cg * cd
-        print(f"{name:6s} s={stride} lo={lh:2d} cg={cg:4d} cd={cd:4d} slabs={nb:4d} {us:7.1f} us {fl / us * 1e-6:7.1f} TFLOP/s", flush=True)
+        mb = (B * (stride * lh) ** 2 * hic + B * lh * lh * loc) * 2 / 1e6        # algorithmic bytes: both operands once
+        print(f"{name:6s} s={stride} lo={lh:2d} cg={cg:4d} cd={cd:4d} slabs={nb:4d} {us:7.1f} us {fl / us * 1e-6:7.1f} TFLOP/s "
+              f"{mb / us:6.2f} TB/s", flush=True)
 
 
 if __name__ == "__main__":
