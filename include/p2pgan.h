@@ -388,6 +388,14 @@ int p2p_sprites_rgba_batch(const void* sprites, int n_sprites, int S, const int*
  * and palettes extracted once at load time (dataset_utils.py:123-164). */
 int p2p_gather_rows_i32(const int* table, int n_rows, int row_ints, const int* sel, int B, int* out, void* stream);
 
+/* palette_ordering = "shuffled" (io_utils.py:53-55 calls tf.random.shuffle inside the dataset map: a new permutation of the
+ * palette's colours every time a sample is loaded).  Re-labels one gathered indexed batch: src_out/tgt_out[b][i] =
+ * inv[b][idx[b][i]] over the n index values of each sample, pal_out[b][j] = palette[b][perm[b][j]] over the P palette rows of C
+ * ints; perm/inv: device int32 [B][P], inverse of each other (the padding rows map to themselves).  The decoded image
+ * indexed_to_rgba(idx, palette) (io_utils.py:96-103) is unchanged. */
+int p2p_palette_relabel_batch(const int* src_idx, const int* tgt_idx, const int* palette, const int* perm, const int* inv,
+                              int B, int n, int P, int C, int* src_out, int* tgt_out, int* pal_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,7 @@ SIGNATURES = {
     "p2p_png_unfilter": [_vp, _i, _i, _i, _vp],
     "p2p_sprites_rgba_batch": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "p2p_gather_rows_i32": [_vp, _i, _i, _vp, _i, _vp, _vp],
+    "p2p_palette_relabel_batch": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
 }
 SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int), "p2p_view_halo_pixels": ([], C.c_int),
            "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),

@@ -65,7 +65,7 @@ __device__ __forceinline__ void hue_rotate(float& r, float& g, float& b, float d
 __global__ __launch_bounds__(256) void sprites_rgba_kernel(const uchar4* __restrict__ sprites, long long sprite_pixels,
                                                            const int* __restrict__ src_idx, const int* __restrict__ tgt_idx,
                                                            const float* __restrict__ aug, int B, int S, int lgS, int normalise,
-                                                           f32x4* __restrict__ source, f32x4* __restrict__ target) {
+                                                           f32x4* __restrict__ source, f32x4* __restrict__ target, int n_sprites) {
     const long long npix = (long long)B * S * S;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(p & (S - 1)), y = (int)((p >> lgS) & (S - 1)), b = (int)(p >> (2 * lgS));
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void sprites_rgba_kernel(const uchar4* __restr
         for (int k = 0; k < 2; ++k) {
             const int sprite = (k ? tgt_idx : src_idx)[b];
             uchar4 u = make_uchar4(0, 0, 0, 0);
-            if (inside) u = sprites[(long long)sprite * sprite_pixels + sy * S + sx];
+            if (inside && sprite >= 0 && sprite < n_sprites) u = sprites[(long long)sprite * sprite_pixels + sy * S + sx];
             float r = u.x, g = u.y, bl = u.z, al = u.w;
             if (u.w == 0) { r = 0.f; g = 0.f; bl = 0.f; }          // blacken_transparent_pixels (dataset_utils.py:11-20)
             if (on) hue_rotate(r, g, bl, delta);
@@ -108,7 +108,8 @@ extern "C" int p2p_sprites_rgba_batch(const void* sprites, int n_sprites, int S,
     long long blocks = ((long long)B * S * S + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     sprites_rgba_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
-        (const uchar4*)sprites, (long long)S * S, src_idx, tgt_idx, aug, B, S, lgS, normalise, (f32x4*)source, (f32x4*)target);
+        (const uchar4*)sprites, (long long)S * S, src_idx, tgt_idx, aug, B, S, lgS, normalise, (f32x4*)source, (f32x4*)target,
+        n_sprites);
     return p2p_check_launch("p2p_sprites_rgba_batch");
 }
 
@@ -116,9 +117,10 @@ extern "C" int p2p_sprites_rgba_batch(const void* sprites, int n_sprites, int S,
 // on the step (no augmentation on this path), so they are extracted once at load time and a batch is a gather of rows:
 // table k has rows of row_ints[k] int32 values; out[k][b] = table[k][sel[b]].
 __global__ __launch_bounds__(256) void gather_rows_kernel(const int* __restrict__ table, int row_ints, const int* __restrict__ sel,
-                                                          int B, int* __restrict__ out) {
+                                                          int B, int* __restrict__ out, int n_rows) {
     const int b = blockIdx.y;
-    const int4* src = (const int4*)(table + (long long)sel[b] * row_ints);
+    const int row = min(max(sel[b], 0), n_rows - 1);           // a selector outside the table never leaves it (the host also checks)
+    const int4* src = (const int4*)(table + (long long)row * row_ints);
     int4* dst = (int4*)(out + (long long)b * row_ints);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_ints / 4; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -128,6 +130,42 @@ extern "C" int p2p_gather_rows_i32(const int* table, int n_rows, int row_ints, c
     P2P_REQUIRE(((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 16) == 0, "p2p_gather_rows_i32: alignment");
     int bx = (row_ints / 4 + 255) / 256;
     if (bx > 16) bx = 16;
-    gather_rows_kernel<<<dim3(bx, B), 256, 0, (hipStream_t)stream>>>(table, row_ints, sel, B, out);
+    gather_rows_kernel<<<dim3(bx, B), 256, 0, (hipStream_t)stream>>>(table, row_ints, sel, B, out, n_rows);
     return p2p_check_launch("p2p_gather_rows_i32");
+}
+
+// palette_ordering = "shuffled" (io_utils.py:53-55: tf.random.shuffle(colors) inside the dataset map, i.e. a NEW permutation
+// every time a sample is loaded): the batch is gathered from the tables in first-appearance order and re-labelled here.
+//   idx_out[b][i]    = inv[b][ idx_in[b][i] ]         (both index maps: the colour that sat at position c now sits at inv[c])
+//   pal_out[b][j][:] = pal_in[b][ perm[b][j] ][:]     (position j holds the colour that sat at perm[j]);  inv[perm[j]] = j
+// so indexed_to_rgba(idx_out, pal_out) == indexed_to_rgba(idx_in, pal_in) pixel for pixel.  Values outside [0, P) are clamped.
+__global__ __launch_bounds__(256) void palette_relabel_kernel(const int* __restrict__ src_in, const int* __restrict__ tgt_in,
+                                                              const int* __restrict__ pal_in, const int* __restrict__ perm,
+                                                              const int* __restrict__ inv, int n, int P, int C,
+                                                              int* __restrict__ src_out, int* __restrict__ tgt_out,
+                                                              int* __restrict__ pal_out) {
+    const int b = blockIdx.y;
+    const int* iv = inv + (long long)b * P;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const long long o = (long long)b * n + i;
+        src_out[o] = iv[min(max(src_in[o], 0), P - 1)];
+        tgt_out[o] = iv[min(max(tgt_in[o], 0), P - 1)];
+    }
+    if (blockIdx.x == 0)
+        for (int e = threadIdx.x; e < P * C; e += blockDim.x) {
+            const int j = e / C, c = e - j * C;
+            const int from = min(max(perm[(long long)b * P + j], 0), P - 1);
+            pal_out[((long long)b * P + j) * C + c] = pal_in[((long long)b * P + from) * C + c];
+        }
+}
+
+extern "C" int p2p_palette_relabel_batch(const int* src_idx, const int* tgt_idx, const int* palette, const int* perm, const int* inv,
+                                         int B, int n, int P, int C, int* src_out, int* tgt_out, int* pal_out, void* stream) {
+    P2P_REQUIRE(src_idx && tgt_idx && palette && perm && inv && src_out && tgt_out && pal_out, "p2p_palette_relabel_batch: null pointer");
+    P2P_REQUIRE(B > 0 && n > 0 && P > 0 && C > 0, "p2p_palette_relabel_batch: bad shape");
+    int bx = (n + 255) / 256;
+    if (bx > 16) bx = 16;
+    palette_relabel_kernel<<<dim3(bx, B), 256, 0, (hipStream_t)stream>>>(src_idx, tgt_idx, palette, perm, inv, n, P, C, src_out,
+                                                                        tgt_out, pal_out);
+    return p2p_check_launch("p2p_palette_relabel_batch");
 }

@@ -20,6 +20,17 @@ from .configuration import (BATCH_SIZE, DATA_FOLDERS, DIRECTION_FOLDERS, IMG_SIZ
                             TEST_SIZES, TRAIN_SIZES)
 
 
+class ShardedBatch(tuple):
+    """A batch that already is ONE RANK'S contiguous shard of a global batch (data parallelism): the tensors hold
+    rows [offset, offset + len) of the `global_batch` samples every rank agreed on.  Unpacks like the plain tuple train_step
+    takes (pix2pix_model.py:64, :297)."""
+
+    def __new__(cls, tensors, global_batch, offset):
+        self = super().__new__(cls, tensors)
+        self.global_batch, self.offset = int(global_batch), int(offset)
+        return self
+
+
 class Dataset:
     """An in-memory, re-iterable sequence of batches (tuples of numpy arrays)."""
 
@@ -200,7 +211,23 @@ class SpriteRGBADataset(Dataset):
         self.sprites = torch.from_numpy(both).to(self.device)            # uint8 [2n][S][S][4], resident
         self.augment, self.batch_size, self.seed = augment, batch_size, seed
         self.epoch = 0
+        self.shard = (0, 1)              # (rank, world): which rows of every global batch make_batch produces
         super().__init__(self._iterate)
+
+    def set_shard(self, rank, world):
+        """data parallelism: every rank draws the SAME shuffle order and augmentation rows (same seed) and materialises only
+        its contiguous share of each batch -- nothing is produced eight times to keep an eighth"""
+        self.shard = (int(rank), int(world))
+        return self
+
+    def unsharded(self):
+        """a view that yields whole batches whatever the shard (evaluation reads the first images of the dataset)"""
+        return Dataset(lambda: self._iterate(shard=(0, 1)))
+
+    def repeat(self):
+        """the TRAINING stream (side2side_model.py:73): epoch k is shuffled by (seed, k), whatever other iterators were taken
+        from this dataset in between (evaluation on one rank must not move the order the other ranks see)"""
+        return Dataset(lambda: itertools.chain.from_iterable(self._iterate(epoch=k) for k in itertools.count()))
 
     def batch_parameters(self, rng, picks):
         """host-side draws of one batch: (int32 [2][B] sprite numbers, f32 [B][4] augmentation rows or None)"""
@@ -221,8 +248,14 @@ class SpriteRGBADataset(Dataset):
         from . import _lib as L
         torch = self.torch
         B = idx.shape[1]
+        if B == 0:       # this rank's share of a ragged batch smaller than the world
+            z = torch.empty((0, self.S, self.S, 4), dtype=torch.float32, device=self.device)
+            return z, z.clone()
+        idx = np.ascontiguousarray(idx)
+        if idx.min() < 0 or idx.max() >= 2 * self.n:
+            raise IndexError(f"sprite numbers must lie in [0, {2 * self.n})")
         idx_d = torch.from_numpy(idx).to(self.device, non_blocking=True)
-        aug_d = torch.from_numpy(aug).to(self.device, non_blocking=True) if aug is not None else None
+        aug_d = torch.from_numpy(np.ascontiguousarray(aug)).to(self.device, non_blocking=True) if aug is not None else None
         src = torch.empty((B, self.S, self.S, 4), dtype=torch.float32, device=self.device)
         tgt = torch.empty_like(src)
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -231,19 +264,31 @@ class SpriteRGBADataset(Dataset):
                C.c_void_p(src.data_ptr()), C.c_void_p(tgt.data_ptr()), st)
         return src, tgt
 
-    def _iterate(self):
-        rng = np.random.default_rng([self.seed, self.epoch])
-        self.epoch += 1
+    def _iterate(self, shard=None, epoch=None):
+        if epoch is None:            # an ad-hoc iteration (evaluation, previews): reshuffled each time like tf.data's shuffle
+            epoch = 1_000_000 + self.epoch
+            self.epoch += 1
+        rank, world = shard or self.shard
+        rng = np.random.default_rng([self.seed, epoch])
         order = rng.permutation(self.n)
         for i in range(0, self.n, self.batch_size):
-            idx, aug = self.batch_parameters(rng, order[i:i + self.batch_size])
-            yield self.make_batch(idx, aug)
+            idx, aug = self.batch_parameters(rng, order[i:i + self.batch_size])       # drawn for the GLOBAL batch on every rank
+            if world == 1:
+                yield self.make_batch(idx, aug)
+                continue
+            from .parallel import shard_bounds
+            Bg = idx.shape[1]
+            lo, hi = shard_bounds(Bg, world, rank)
+            yield ShardedBatch(self.make_batch(idx[:, lo:hi], aug[lo:hi] if aug is not None else None), Bg, lo)
 
 
 class SpriteIndexedDataset(Dataset):
-    """load_indexed_ds's train or test dataset (dataset_utils.py:123-164,232-246).  Nothing on this path is random per step,
-    so the union palette of every pair and both index maps are extracted once here (io_utils.py) and live in HBM as int32
-    tables; a batch is three row gathers."""
+    """load_indexed_ds's train or test dataset (dataset_utils.py:123-164,232-246).  The union palette of every pair and both
+    index maps are extracted once here (io_utils.py) and live in HBM as int32 tables; a batch is three row gathers.  For the
+    deterministic orderings ("grayness", "top2bottom", "bottom2top") nothing on this path is random per step.  "shuffled" is:
+    the reference shuffles the colours inside the dataset map (io_utils.py:53-55), i.e. every time a sample is loaded, so the
+    tables keep the first-appearance order and every batch draws a fresh permutation per sample, applied by one launch
+    (p2p_palette_relabel_batch: palette rows permuted, both index maps re-labelled through the inverse)."""
 
     def __init__(self, source_sprites, target_sprites, palette_ordering, batch_size=BATCH_SIZE, seed=SEED, device=None):
         import torch
@@ -251,27 +296,54 @@ class SpriteIndexedDataset(Dataset):
         self.torch = torch
         self.device = torch.device(device or "cuda:0")
         self.n, self.S = len(source_sprites), source_sprites.shape[1]
-        rng = np.random.default_rng([seed, 7])
+        self.palette_ordering = palette_ordering
+        self.reshuffle = palette_ordering not in ("grayness", "top2bottom", "bottom2top")
         src_idx = np.empty((self.n, self.S, self.S, 1), np.int32)
         tgt_idx = np.empty_like(src_idx)
         pal = np.empty((self.n, MAX_PALETTE_SIZE, 4), np.int32)
+        self.ncolors = np.empty(self.n, np.int32)            # distinct colours of each pair (the rest of a palette is padding)
         for k in range(self.n):
             s = blacken_transparent_pixels(source_sprites[k]).astype(np.int32)
             t = blacken_transparent_pixels(target_sprites[k]).astype(np.int32)
-            pal[k] = io_utils.extract_palette(np.concatenate([s, t], axis=-1), palette_ordering, rng=rng)
+            both = np.concatenate([s, t], axis=-1)
+            pal[k] = io_utils.extract_palette(both, "top2bottom" if self.reshuffle else palette_ordering)
+            self.ncolors[k] = len(io_utils._unique_rows_first_appearance(both.reshape(-1, 4))[0])
             src_idx[k] = io_utils.rgba_to_indexed(s, pal[k])
             tgt_idx[k] = io_utils.rgba_to_indexed(t, pal[k])
         self.tables = [torch.from_numpy(a.reshape(self.n, -1)).to(self.device) for a in (src_idx, tgt_idx, pal)]
         self.shapes = [(self.S, self.S, 1), (self.S, self.S, 1), (MAX_PALETTE_SIZE, 4)]
         self.batch_size, self.seed, self.epoch = batch_size, seed, 0
+        self.shard = (0, 1)
         super().__init__(self._iterate)
 
-    def make_batch(self, picks):
+    set_shard = SpriteRGBADataset.set_shard
+    unsharded = SpriteRGBADataset.unsharded
+    repeat = SpriteRGBADataset.repeat
+
+    def palette_permutations(self, rng, picks):
+        """per sample: perm (position j takes the colour at perm[j]) over its real colours, identity over the padding; and the
+        inverse.  int32 [B][MAX_PALETTE_SIZE] each"""
+        B = len(picks)
+        perm = np.tile(np.arange(MAX_PALETTE_SIZE, dtype=np.int32), (B, 1))
+        inv = perm.copy()
+        for b, k in enumerate(picks):
+            nc = int(self.ncolors[k])
+            p = rng.permutation(nc).astype(np.int32)
+            perm[b, :nc] = p
+            inv[b, p] = np.arange(nc, dtype=np.int32)
+        return perm, inv
+
+    def make_batch(self, picks, relabel=None):
         import ctypes as C
         from . import _lib as L
         torch = self.torch
+        picks = np.asarray(picks, np.int32)
         B = len(picks)
-        sel = torch.from_numpy(np.asarray(picks, np.int32)).to(self.device, non_blocking=True)
+        if B == 0:
+            return tuple(torch.empty((0,) + shape, dtype=torch.int32, device=self.device) for shape in self.shapes)
+        if picks.min() < 0 or picks.max() >= self.n:
+            raise IndexError(f"sample numbers must lie in [0, {self.n})")
+        sel = torch.from_numpy(np.ascontiguousarray(picks)).to(self.device, non_blocking=True)
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         out = []
         for table, shape in zip(self.tables, self.shapes):
@@ -279,14 +351,32 @@ class SpriteIndexedDataset(Dataset):
             L.call("p2p_gather_rows_i32", C.c_void_p(table.data_ptr()), self.n, table.shape[1], C.c_void_p(sel.data_ptr()), B,
                    C.c_void_p(o.data_ptr()), st)
             out.append(o)
+        if relabel is not None:
+            perm, inv = (torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=True) for a in relabel)
+            res = [torch.empty_like(o) for o in out]
+            L.call("p2p_palette_relabel_batch", C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
+                   C.c_void_p(out[2].data_ptr()), C.c_void_p(perm.data_ptr()), C.c_void_p(inv.data_ptr()), B, self.S * self.S,
+                   MAX_PALETTE_SIZE, 4, C.c_void_p(res[0].data_ptr()), C.c_void_p(res[1].data_ptr()), C.c_void_p(res[2].data_ptr()), st)
+            out = res
         return tuple(out)
 
-    def _iterate(self):
-        rng = np.random.default_rng([self.seed, self.epoch])
-        self.epoch += 1
+    def _iterate(self, shard=None, epoch=None):
+        if epoch is None:
+            epoch = 1_000_000 + self.epoch
+            self.epoch += 1
+        rank, world = shard or self.shard
+        rng = np.random.default_rng([self.seed, epoch])
         order = rng.permutation(self.n)
         for i in range(0, self.n, self.batch_size):
-            yield self.make_batch(order[i:i + self.batch_size])
+            picks = order[i:i + self.batch_size]
+            relabel = self.palette_permutations(rng, picks) if self.reshuffle else None      # drawn for the GLOBAL batch on every rank
+            if world == 1:
+                yield self.make_batch(picks, relabel)
+                continue
+            from .parallel import shard_bounds
+            lo, hi = shard_bounds(len(picks), world, rank)
+            rl = (relabel[0][lo:hi], relabel[1][lo:hi]) if relabel is not None else None
+            yield ShardedBatch(self.make_batch(picks[lo:hi], rl), len(picks), lo)
 
 
 def _pair_sprites(source_direction, target_direction, split, sizes, data_folders, root):

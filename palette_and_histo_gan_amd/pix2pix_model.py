@@ -17,10 +17,12 @@ reference's signatures for standalone evaluation, but a SUBCLASS that overrides 
 train_step detects that and raises instead of silently ignoring the override.
 Extra keyword arguments (dtype, img_size, device, data_parallel, seed) are build-added; defaults reproduce the reference.
 
-Data parallelism (build-added): with `data_parallel`, every rank is handed the same GLOBAL batch (same
-dataset, same order) and takes its contiguous shard (parallel.shard_bounds); loss denominators use the global batch, the
-dropout stream is keyed by the global sample index, gradients are summed over ranks.  Ragged global batches and ranks with
-an empty shard are handled.
+Data parallelism (build-added): with `data_parallel`, every rank agrees on the same GLOBAL batch (same
+dataset seed, same order) and works on its contiguous shard (parallel.shard_bounds).  The sprite datasets of dataset_utils
+are told their shard (set_shard) and MATERIALISE ONLY THAT SHARE of every batch (dataset_utils.ShardedBatch carries the global
+batch size and the shard's offset); any other batch source is taken as the whole global batch and sliced here.  Loss
+denominators use the global batch, the dropout stream is keyed by the global sample index, gradients are summed over ranks.
+Ragged global batches and ranks with an empty shard are handled.
 """
 import torch
 
@@ -29,6 +31,7 @@ from . import histogram as _histogram  # noqa: F401  (module parity with the ref
 from .configuration import IMG_SIZE, MAX_PALETTE_SIZE
 from .engine import Pix2PixEngine
 from .networks import PatchDiscriminator, UnetGenerator
+from .dataset_utils import ShardedBatch
 from .parallel import shard_bounds
 from .side2side_model import Checkpoint, CheckpointManager, S2SModel
 
@@ -48,10 +51,18 @@ class BinaryCrossentropy:
 
 
 class CategoricalCrossentropy:
-    """tf.keras.losses.CategoricalCrossentropy(from_logits=False) (pix2pix_model.py:265) on probabilities: Keras' fallback
-    formula p /= sum p; p = clip(p, 1e-7, 1 - 1e-7); mean over pixels of -sum t log p."""
+    """tf.keras.losses.CategoricalCrossentropy(from_logits=False) (pix2pix_model.py:265) for standalone evaluation.
+    Keras 2.9 evaluates it on the logits cached by the softmax activation (softmax_cross_entropy_with_logits) -- that is what
+    train_step's fused kernel computes (log-sum-exp form, csrc/softmax.hip) and what `logits=` selects here.  Handed
+    probabilities alone, Keras' documented fallback applies: p /= sum p; p = clip(p, 1e-7, 1 - 1e-7); mean of -sum t log p.
+    The two agree to < 1e-6 unless a target probability is below 1e-7, where the fallback is capped at -log 1e-7 = 16.1 per
+    pixel and the logits form is not."""
 
-    def __call__(self, y_true, y_pred):
+    def __call__(self, y_true, y_pred, logits=None):
+        if logits is not None:
+            z = torch.as_tensor(logits, dtype=torch.float32)
+            t = torch.as_tensor(y_true, dtype=torch.float32).to(z.device)
+            return -(t * torch.log_softmax(z, dim=-1)).sum(-1).mean()
         p = torch.as_tensor(y_pred, dtype=torch.float32)
         t = torch.as_tensor(y_true, dtype=torch.float32).to(p.device)
         p = p / p.sum(-1, keepdim=True)
@@ -83,6 +94,8 @@ class Pix2PixModel(S2SModel):
         self._dtype = {"bf16": L.BF16, "f32": L.F32}[dtype] if isinstance(dtype, str) else dtype
         self._img_size, self._device, self._seed = img_size, device, seed
         self.data_parallel = data_parallel
+        if data_parallel is not None and hasattr(train_ds, "set_shard"):
+            train_ds.set_shard(data_parallel.rank, data_parallel.world)      # produce this rank's rows only
 
         self.generator = self.create_generator()
         self.discriminator = self.create_discriminator()
@@ -162,9 +175,11 @@ class Pix2PixModel(S2SModel):
                     f"(engine.train_step_*) or subclass train_step.")
         self._hooks_checked = True
 
-    def _shard(self, tensors):
+    def _shard(self, batch, tensors):
         """(local shard of every tensor, global batch, samples in front of the shard, DataParallel or None)"""
         dp = self.data_parallel
+        if isinstance(batch, ShardedBatch):       # the dataset produced this rank's rows only
+            return tensors, batch.global_batch, batch.offset, dp
         Bg = len(tensors[0])
         if dp is None:
             return tensors, Bg, 0, None
@@ -175,7 +190,7 @@ class Pix2PixModel(S2SModel):
         """pix2pix_model.py:62-89"""
         self._check_hooks()
         source_image, real_image = batch
-        (src, real), Bg, lo, dp = self._shard([source_image, real_image])
+        (src, real), Bg, lo, dp = self._shard(batch, [source_image, real_image])
         if len(src) == 0:
             out = self.engine.train_step_empty(self.lambda_l1, dp=dp)
         else:
@@ -210,8 +225,8 @@ class Pix2PixModel(S2SModel):
         """pix2pix_model.py:103-110"""
         num_train_examples = number_of_examples // 2
         num_test_examples = number_of_examples - num_train_examples
-        train_examples = self.train_ds.unbatch().take(num_train_examples).batch(1)
-        test_examples = self.test_ds.unbatch().take(num_test_examples).batch(1)
+        train_examples = self._whole(self.train_ds).unbatch().take(num_train_examples).batch(1)
+        test_examples = self._whole(self.test_ds).unbatch().take(num_test_examples).batch(1)
         return list(test_examples.as_numpy_iterator()) + list(train_examples.as_numpy_iterator())
 
     def evaluate_l1_batch(self, batch):
@@ -248,7 +263,7 @@ class Pix2PixHistogramModel(Pix2PixAugmentedModel):
     def train_step(self, batch, step, update_steps):
         self._check_hooks()
         source_image, real_image = batch
-        (src, real), Bg, lo, dp = self._shard([source_image, real_image])
+        (src, real), Bg, lo, dp = self._shard(batch, [source_image, real_image])
         if len(src) == 0:
             out = self.engine.train_step_empty(self.lambda_l1, lambda_hist=self.lambda_histogram, dp=dp)
         else:
@@ -313,7 +328,7 @@ class Pix2PixIndexedModel(Pix2PixModel):
         """pix2pix_model.py:295-325"""
         self._check_hooks()
         source_image, real_image, _ = batch
-        (src, real), Bg, lo, dp = self._shard([source_image, real_image])
+        (src, real), Bg, lo, dp = self._shard(batch, [source_image, real_image])
         if len(src) == 0:
             out = self.engine.train_step_empty(0.0, lambda_aux=self.lambda_segmentation, dp=dp)
         else:

@@ -151,25 +151,45 @@ class S2SModel(ABC):
         self.architecture_name = architecture_name
         self.checkpoint_dir = os.sep.join([TEMP_FOLDER, "training-checkpoints", self.architecture_name, self.model_name])
 
+    @property
+    def is_main_rank(self):
+        """data parallelism (build-added): rank 0 owns every side effect of fit() -- the log folder, the TensorBoard event file,
+        previews, evaluation callbacks, console output and checkpoints; the other ranks only train"""
+        dp = getattr(self, "data_parallel", None)
+        return dp is None or dp.rank == 0
+
+    @staticmethod
+    def _whole(dataset):
+        """evaluation / preview view of a dataset: whole batches whatever the training shard (dataset_utils.set_shard)"""
+        return dataset.unsharded() if hasattr(dataset, "unsharded") else dataset
+
+    def _rank_barrier(self):
+        dp = getattr(self, "data_parallel", None)
+        if dp is not None:
+            dp.barrier()
+
     def fit(self, steps, update_steps, callbacks=[], starting_step=0):
         """side2side_model.py:54-65"""
-        if starting_step == 0:
+        if starting_step == 0 and self.is_main_rank:
             self.log_folders = [TEMP_FOLDER, "logs", self.architecture_name, self.model_name]
             self.now_string = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
             self.summary_writer = ScalarLog(os.sep.join([*self.log_folders, self.now_string]))
         try:
             self.do_fit(steps, update_steps, callbacks, starting_step)
         finally:
-            self.summary_writer.flush()
+            if self.summary_writer is not None:
+                self.summary_writer.flush()
+            self._rank_barrier()        # nobody leaves fit() before rank 0 has written its last checkpoint and log rows
 
     def do_fit(self, steps, update_steps=1000, callbacks=[], starting_step=0):
         """side2side_model.py:67-122"""
-        examples = self.select_examples_for_visualization()
+        main = self.is_main_rank
+        examples = self.select_examples_for_visualization() if main else []
         training_start_time = time.time()
         step_start_time = training_start_time
         for step, batch in self.train_ds.repeat().take(steps).enumerate():
             step += starting_step
-            if (step + 1) % update_steps == 0 or step == 0:
+            if main and ((step + 1) % update_steps == 0 or step == 0):
                 if step != 0:
                     show_eta(training_start_time, step_start_time, step, starting_step, steps, update_steps)
                 step_start_time = time.time()
@@ -183,8 +203,8 @@ class S2SModel(ABC):
                     print("FID needs the InceptionV3 ImageNet weights (network fetch): skipped")
                 print(f"Step: {(step + 1) / 1000}k")
             self.train_step(batch, step, update_steps)
-            if (step + 1) % (update_steps * 5) == 0 or (step - starting_step + 1) == steps:
-                self.checkpoint_manager.save()
+            if main and ((step + 1) % (update_steps * 5) == 0 or (step - starting_step + 1) == steps):
+                self.checkpoint_manager.save()      # every rank holds the same weights and Adam state: one copy on disk
 
     @abstractmethod
     def train_step(self, batch, step, UPDATE_STEPS):
@@ -231,7 +251,7 @@ class S2SModel(ABC):
         is_test = dataset_name == "test"
         limit = TEST_SIZE if is_test else TRAIN_SIZE
         num_images = limit if num_images is None else min(num_images, limit)
-        dataset = list((self.test_ds if is_test else self.train_ds).unbatch().take(num_images).batch(1).as_numpy_iterator())
+        dataset = list(self._whole(self.test_ds if is_test else self.train_ds).unbatch().take(num_images).batch(1).as_numpy_iterator())
         base = os.sep.join([TEMP_FOLDER, "generated-images", self.architecture_name, self.model_name])
         shutil.rmtree(base, ignore_errors=True)
         os.makedirs(base, exist_ok=True)
@@ -254,7 +274,7 @@ class S2SModel(ABC):
 
     def show_discriminated_images(self, dataset_name="test", num_images=2):
         """side2side_model.py:228-239 (numbers instead of plots)"""
-        dataset = self.test_ds if dataset_name == "test" else self.train_ds
+        dataset = self._whole(self.test_ds if dataset_name == "test" else self.train_ds)
         res = []
         for images in list(dataset.unbatch().take(num_images).batch(1).as_numpy_iterator()):
             res.append(self.debug_discriminator_patches(images))
@@ -267,6 +287,7 @@ class S2SModel(ABC):
         batch of one like the reference does; indexed batches are looked up in their palette (io_utils.py:96-103)."""
         from . import io_utils
         real, fake = [], []
+        dataset = self._whole(dataset)
         for batch in dataset.unbatch().take(num_images).batch(1):
             out = self.generate(batch)
             host = lambda t: (t.detach().cpu() if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t)))   # noqa: E731

@@ -101,6 +101,83 @@ def test_two_rank_models_equal_one_rank(tmp_path, monkeypatch):
         assert np.abs(p2 - p1).max() < 3e-5, tag       # same Adam step (rounding-level gradients may move by a fraction of lr)
 
 
+def _fit_worker(rank, world, port, q, tmp):
+    """S2SModel.fit() under data parallelism: the sprite dataset produces this rank's rows only, rank 0 alone writes logs,
+    previews and checkpoints, every rank ends with the same weights"""
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(int(os.environ.get("P2P_TEST_DUMP_AFTER", "240")), exit=True, file=sys.stderr)
+    os.chdir(tmp)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    try:
+        comm = PAR.DataParallel("cuda:0", backend="gloo") if world > 1 else None
+        train, test = D.load_rgba_ds(2, 3, augment=True, batch_size=4, train_sizes=[10], test_sizes=[3], device="cuda:0", seed=5)
+        m = M.Pix2PixModel(train, test, "front2right", f"dp-fit-w{world}", 100.0, dtype="f32", data_parallel=comm, seed=5)
+        sizes = []
+        orig = m.engine.train_step_rgba
+
+        def spy(src, *a, **kw):
+            sizes.append((int(src.shape[0]), kw.get("global_batch"), kw.get("batch_offset")))
+            return orig(src, *a, **kw)
+        m.engine.train_step_rgba = spy
+        m.fit(5, 2, callbacks=["evaluate_l1"])          # 10 sprites, batch 4: global batches 4, 4, 2 (ragged), 4, 4
+        torch.cuda.synchronize()
+        q.put(("fit", rank, world, m.engine.G.params.cpu().numpy().copy(), m.engine.D.params.cpu().numpy().copy(), sizes,
+               m.summary_writer is not None, list(m.checkpoint_manager.saved)))
+        if comm is not None:
+            comm.barrier()
+            comm.destroy()
+    except BaseException:
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+    q.close()
+    q.join_thread()
+    os._exit(0)
+
+
+@pytest.mark.timeout(1200)
+def test_two_rank_fit_equals_one_rank_fit(tmp_path):
+    """sharded batch production + rank-aware fit().  Datasets written once, then a 1-rank fit and a
+    2-rank fit (gloo transport, both ranks on the test box's GPU) of the same 5 steps over a ragged epoch."""
+    from tests import sprite_fixtures as F
+    F.write_dataset(str(tmp_path), 10, 3, directions=(2, 3))
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world, port in ((1, 29661), (2, 29662)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_fit_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+        for p in procs:
+            p.start()
+        for _ in range(world):
+            item = q.get(timeout=600)
+            if item[0] == "error":
+                for p in procs:
+                    p.kill()
+                pytest.fail(f"rank {item[1]} (world {world}) failed:\n{item[2]}")
+            results[(world, item[1])] = item[3:]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    g1, d1, sizes1, log1, ck1 = results[(1, 0)]
+    ga, da, sizes_a, log_a, ck_a = results[(2, 0)]
+    gb, db, sizes_b, log_b, ck_b = results[(2, 1)]
+    # each rank was handed ITS rows of every global batch, with the global size and its offset
+    assert [s[0] for s in sizes1] == [4, 4, 2, 4, 4]
+    assert sizes_a == [(2, 4, 0), (2, 4, 0), (1, 2, 0), (2, 4, 0), (2, 4, 0)]
+    assert sizes_b == [(2, 4, 2), (2, 4, 2), (1, 2, 1), (2, 4, 2), (2, 4, 2)]
+    # rank 0 alone logs and checkpoints; the checkpoint exists once
+    assert log_a and not log_b and len(ck_a) == 1 and ck_b == []
+    ck_dir = os.path.join(str(tmp_path), os.path.dirname(ck_a[0]))
+    assert sorted(os.listdir(ck_dir)) == [os.path.basename(ck_a[0])]
+    # both ranks hold the same weights, and they are the 1-rank run's (f32 summation order, five Adam steps)
+    assert np.array_equal(ga, gb) and np.array_equal(da, db)
+    assert np.abs(ga - g1).max() < 2e-4 and np.abs(da - d1).max() < 2e-4, (np.abs(ga - g1).max(), np.abs(da - d1).max())
+
+
 @pytest.mark.timeout(600)
 def test_world1_rccl_step_matches_plain_step(tmp_path, monkeypatch):
     """One process, one rank, backend nccl (RCCL): the bucketed asynchronous all-reduces issued from the weight-gradient

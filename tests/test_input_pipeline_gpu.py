@@ -105,6 +105,68 @@ def test_load_indexed_ds_end_to_end(tmp_path, monkeypatch):
     assert model.engine.G.t == 2
 
 
+def test_shuffled_palette_ordering_is_redrawn_every_time_a_sample_is_loaded(tmp_path, monkeypatch):
+    """io_utils.py:53-55 shuffles the colours inside the dataset map: the same sprite gets a different palette
+    order in different epochs, while the image it decodes to (io_utils.py:96-103) never changes; the other orderings are fixed"""
+    from palette_and_histo_gan_amd import io_utils
+    monkeypatch.chdir(tmp_path)
+    data = F.write_dataset(str(tmp_path), 6, 3, directions=(0, 1))
+    train, _ = D.load_indexed_ds(0, 1, "shuffled", batch_size=6, train_sizes=[6], test_sizes=[3], device=DEV)
+    assert train.reshuffle
+    want = {}
+    for k in range(6):
+        want[k] = (D.blacken_transparent_pixels(data[("train", 0)][k]).astype(np.int64), D.blacken_transparent_pixels(data[("train", 1)][k]).astype(np.int64))
+    palettes = []
+    for epoch in range(3):
+        (src, tgt, pal), = list(train)
+        src, tgt, pal = src.cpu().numpy(), tgt.cpu().numpy(), pal.cpu().numpy()
+        seen = {}
+        for b in range(6):
+            dec_s, dec_t = io_utils.indexed_to_rgba(src[b], pal[b]), io_utils.indexed_to_rgba(tgt[b], pal[b])
+            k = [k for k in range(6) if np.array_equal(dec_s, want[k][0]) and np.array_equal(dec_t, want[k][1])]
+            assert k, "a re-labelled pair must decode to one of the sprite pairs"
+            nc = int(train.ncolors[k[0]])
+            assert (src[b] < nc).all() and (tgt[b] < nc).all()
+            assert (pal[b][nc:] == np.array([255, 0, 220, 255])).all()          # the padding stays behind the colours
+            seen[k[0]] = pal[b][:nc].copy()
+        assert sorted(seen) == list(range(6))
+        palettes.append(seen)
+    changed = sum(not np.array_equal(palettes[0][k], palettes[e][k]) for k in range(6) for e in (1, 2))
+    assert changed >= 8, "12 redraws of 4..11-colour palettes: almost all must differ from the first epoch's order"
+    for k in range(6):          # ... and each is a permutation of the same colours
+        assert sorted(map(tuple, palettes[0][k])) == sorted(map(tuple, palettes[2][k]))
+    # a fixed ordering is the same in every epoch
+    fixed, _ = D.load_indexed_ds(0, 1, "grayness", batch_size=6, train_sizes=[6], test_sizes=[3], device=DEV)
+    assert not fixed.reshuffle
+    model = M.Pix2PixIndexedModel(train, _, "back2left", "pix2pix-indexed-shuffled", lambda_segmentation=0.5)
+    model.fit(2, 2)
+    assert model.engine.G.t == 2
+
+
+def test_load_generator_leaves_the_discriminator_and_both_optimizers_alone(tmp_path, monkeypatch):
+    """side2side_model.py:186-188 replaces ONE network"""
+    monkeypatch.chdir(tmp_path)
+    ds = D.synthetic_rgba_ds(4, batch_size=4, seed=3)
+    m = M.Pix2PixModel(ds, ds, "front2right", "save-load", 100.0, dtype="f32")
+    m.train_step(next(iter(ds)), 0, 1)
+    m.save_generator()
+    e = m.engine
+    g_saved = e.G.params.clone()
+    m.train_step(next(iter(ds)), 1, 1)                       # weights, moments and step counts move on
+    snap = {(sid, k): getattr(st, k).clone() for sid, st in (("G", e.G), ("D", e.D)) for k in ("m", "v")}
+    d_now, t_now = e.D.params.clone(), (e.G.t, e.D.t)
+    assert not torch.equal(e.G.params, g_saved)
+    m.load_generator()
+    assert torch.equal(e.G.params, g_saved)
+    assert torch.equal(e.D.params, d_now) and (e.G.t, e.D.t) == t_now
+    for sid, st in (("G", e.G), ("D", e.D)):
+        for k in ("m", "v"):
+            assert torch.equal(getattr(st, k), snap[(sid, k)]), (sid, k)
+    m2 = M.Pix2PixModel(ds, ds, "front2right", "save-load", 100.0, dtype="f32")
+    m2.load_generator()
+    assert torch.equal(m2.engine.G.params, g_saved) and m2.engine.G.t == 0 and float(m2.engine.G.m.abs().max()) == 0.0
+
+
 def test_notebook_script_runs_end_to_end(tmp_path):
     """examples/experiments.py = the workflow of experiments.ipynb against this build: every model kind trains, evaluates, saves"""
     import subprocess
