@@ -129,7 +129,22 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one captured hipGraph (N=1 only). Measured "
                     "slower than eager two-stream launching on ROCm 7.2 (the replay serialises the weight-gradient branch), so off by default")
     ap.add_argument("--detail", default=None, help="write a per-call (entry point, shape) device-time table to this file")
+    # RCCL tuning for the gradient all-reduce (N > 1).  xGMI is point-to-point, 7 links x ~153 GB/s per GPU: a single ring moves
+    # 2 x 7/8 x 117 MB over one link direction (>= 1.34 ms); more channels light more links.  Unset = RCCL's
+    # own choice.  No N > 1 measurement exists from this build's one-GPU boxes: the knobs are here for the 8-GPU node.
+    ap.add_argument("--rccl-channels", type=int, default=None, help="NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS")
+    ap.add_argument("--rccl-algo", default=None, help="NCCL_ALGO (Ring | Tree)")
+    ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO (Simple | LL | LL128)")
+    ap.add_argument("--bucket-mb", type=float, default=None, help="minimum size of a gradient bucket (default 16 MB)")
     args = ap.parse_args()
+    if args.rccl_channels:
+        os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
+    if args.rccl_algo:
+        os.environ["NCCL_ALGO"] = args.rccl_algo
+    if args.rccl_proto:
+        os.environ["NCCL_PROTO"] = args.rccl_proto
+    if args.bucket_mb:
+        E.ParamStore.BUCKET_MIN = int(args.bucket_mb * 1024 * 1024 / 4)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -200,7 +215,9 @@ def main():
                                + ("palette-index sprites (1 -> 256-way softmax), " f"lambda_seg={lam_l1}" if indexed else
                                   "RGBA sprites, " f"lambda_l1={lam_l1}") + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
                    "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if use_graph else "eager"},
+                   "launch": "hipGraph replay" if use_graph else "eager",
+                   **({"rccl": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MAX_NCHANNELS") if k in os.environ},
+                       "grad_buckets": len(eng.G.buckets)} if world > 1 else {})},
         "losses": [round(float(x), 5) for x in losses.cpu().numpy()],
     }
 

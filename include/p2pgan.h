@@ -260,6 +260,20 @@ int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fak
  * transposed and before its division by the per-image total, histogram.py:75-79). */
 int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tensor* img, float* hist, void* stream);
 
+/* The same raw histograms [N][3][64][64], all three colour components of an image from THREE shared kernel rows per pixel
+ * (the components' (u, v) are (a, b), (-a, c), (-b, -c) of three log-chroma differences and the bin grid is symmetric,
+ * histogram.py:54-55,72-74), contracted over the image's pixels or -- where `points`/`npoints` (p2p_rgbuv_points) list them
+ * -- over its DISTINCT colours weighted by their pixel counts (identical up to f32 summation order).  workspace:
+ * p2p_rgbuv_hist_fwd3_workspace_bytes(N) bytes (partial histograms of the pixel ranges, summed in fixed order). */
+long long p2p_rgbuv_hist_fwd3_workspace_bytes(int N);
+int p2p_rgbuv_hist_fwd3(int dtype, int N, int H, int W, const p2p_tensor* img, const float* points, const int* npoints, int cap,
+                        float* hist, float* workspace, void* stream);
+/* Distinct colours of every image with their pixel counts: points[n][k] = (r, g, b, count) for k < npoints[n], in order of
+ * first appearance within tiles of 1024 pixels (bitwise equality of the f32 / bf16 RGB values; colours of different tiles
+ * are not merged).  npoints[n] = -1 where the list would exceed `cap` entries (the image is then contracted densely).
+ * Deterministic (integer LDS atomics only).  points: f32 [N][cap][4], 16-byte aligned. */
+int p2p_rgbuv_points(int dtype, int N, int H, int W, const p2p_tensor* img, int cap, float* points, int* npoints, void* stream);
+
 /* out[N][64][64][3] = raw[N][3][64][64] transposed and divided by the per-image total (histogram.py:75-79). */
 int p2p_hist_normalize(const float* raw, int N, float* out, void* stream);
 

@@ -65,6 +65,8 @@ SIGNATURES = {
     "p2p_dropout_mask": [_vp, _ll, _ll, _ll, _vp],
     "p2p_rgbuv_hist_fwd": [_i, _i, _i, _i, _TP, _vp, _vp],
     "p2p_hist_normalize": [_vp, _i, _vp, _vp],
+    "p2p_rgbuv_hist_fwd3": [_i, _i, _i, _i, _TP, _vp, _vp, _i, _vp, _vp, _vp],
+    "p2p_rgbuv_points": [_i, _i, _i, _i, _TP, _i, _vp, _vp, _vp],
     "p2p_hellinger_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "p2p_hellinger_finish": [_vp, _f, _vp, _vp],
     "p2p_rgbuv_hist_hellinger_bwd": [_i, _i, _i, _i, _TP, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
@@ -91,6 +93,7 @@ SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int), "p2
            "p2p_conv_fewout_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgrad_small_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong),
+           "p2p_rgbuv_hist_fwd3_workspace_bytes": ([_i], C.c_longlong),
            "p2p_view_colsum_workspace_bytes": ([_i, _i, _i, _i, _i, _TP], C.c_longlong),
            "p2p_weight_prep_task_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_longlong)}
 

@@ -91,6 +91,185 @@ __global__ __launch_bounds__(256) void rgbuv_hist_fwd_kernel(int H, int W, TView
     }
 }
 
+// ---- colour points: the distinct colours of an image with their pixel counts ----------------------------------------------
+// Iy, u and v of a pixel depend on its RGB value alone, so  H_c[i][j] = sum over DISTINCT colours of count * Iy * ku[i] * kv[j].
+// A palette sprite (the REAL image of every step: 10-54 colours in the reference's dataset, hue rotation maps colour to colour,
+// translation moves pixels) has two orders of magnitude fewer colours than pixels.  One workgroup per image walks the image in
+// tiles of 1024 pixels; inside a tile equal colours (bitwise equal f32 RGB) meet in an LDS hash table, every pixel learns
+// whether it is the FIRST pixel of its colour in the tile, and the first pixels append (r, g, b, count) to the image's list in
+// pixel order.  Integer LDS atomics only: the list (content and order) does not depend on scheduling.  Tiles do not merge
+// with each other (the contributions are additive).  An image whose list would exceed `cap` entries is marked dense
+// (npoints = -1): the histogram kernel then reads its pixels.
+#define PT_TILE 1024
+#define PT_SLOTS 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void rgbuv_points_kernel(int H, int W, TView img, int cap, f32x4* __restrict__ points,
+                                                          int* __restrict__ npoints) {
+    __shared__ float px[PT_TILE][3];
+    __shared__ int owner[PT_SLOTS];          // pixel (tile-local) that claimed the slot, -1 = empty
+    __shared__ int cnt[PT_SLOTS], rep[PT_SLOTS];
+    __shared__ int wsum[4];
+    __shared__ int base_s, dense_s;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = H * W;
+    f32x4* out = points + (long long)n * cap;
+    if (tid == 0) { base_s = 0; dense_s = 0; }
+    for (int t0 = 0; t0 < HW; t0 += PT_TILE) {
+        for (int s = tid; s < PT_SLOTS; s += 256) { owner[s] = -1; cnt[s] = 0; rep[s] = 0x7fffffff; }
+        for (int q = tid; q < PT_TILE; q += 256) {
+            const int p = t0 + q;
+            float x[3] = {0.f, 0.f, 0.f};
+            if (p < HW) {
+                const int yy = p / W, xx = p - yy * W;
+                const T* g = (const T*)img.ptr + img.off(n, yy, xx);
+                x[0] = to_f32(g[0]); x[1] = to_f32(g[1]); x[2] = to_f32(g[2]);
+            }
+            px[q][0] = x[0]; px[q][1] = x[1]; px[q][2] = x[2];
+        }
+        __syncthreads();
+        int slot[PT_TILE / 256];
+#pragma unroll
+        for (int k = 0; k < PT_TILE / 256; ++k) {
+            const int q = tid + 256 * k;       // pixels of one thread are 256 apart: the prefix sum below runs per k
+            slot[k] = -1;
+            if (t0 + q >= HW) continue;
+            const unsigned b0 = __float_as_uint(px[q][0]), b1 = __float_as_uint(px[q][1]), b2 = __float_as_uint(px[q][2]);
+            unsigned h = (b0 * 0x9E3779B1u) ^ (b1 * 0x85EBCA77u) ^ (b2 * 0xC2B2AE3Du);
+            h ^= h >> 15;
+            int sl = (int)(h & (PT_SLOTS - 1));
+            for (int probe = 0; probe < PT_SLOTS; ++probe) {
+                int o = atomicCAS(&owner[sl], -1, q);
+                if (o == -1) o = q;
+                if (__float_as_uint(px[o][0]) == b0 && __float_as_uint(px[o][1]) == b1 && __float_as_uint(px[o][2]) == b2) break;
+                sl = (sl + 1) & (PT_SLOTS - 1);
+            }
+            slot[k] = sl;
+            atomicAdd(&cnt[sl], 1);
+            atomicMin(&rep[sl], q);
+        }
+        __syncthreads();
+        // first pixels in pixel order: q = tid + 256 k, so order = (k, tid): one block-wide exclusive scan per k
+        int base = base_s;
+#pragma unroll
+        for (int k = 0; k < PT_TILE / 256; ++k) {
+            const int q = tid + 256 * k;
+            const int first = (slot[k] >= 0 && rep[slot[k]] == q) ? 1 : 0;
+            int incl = first;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 4; ++w) { if (w < wave) before += wsum[w]; total += wsum[w]; }
+            const int pos = base + before + incl - first;
+            if (first && pos < cap) {
+                f32x4 e = {px[q][0], px[q][1], px[q][2], (float)cnt[slot[k]]};
+                out[pos] = e;
+            }
+            base += total;
+            __syncthreads();
+        }
+        if (tid == 0) { base_s = base; if (base > cap) dense_s = 1; }
+        __syncthreads();
+    }
+    if (tid == 0) npoints[n] = dense_s ? -1 : base_s;
+}
+
+// ---- forward, all three components of an image in one workgroup ------------------------------------------------------------
+// The three (comp, p1, p2) orders of histogram.py:72-74 use only three log-chroma differences, a = lR - lG, b = lR - lB,
+// c = lG - lB:  (u, v) = (a, b), (-a, c), (-b, -c); and the bin centres are symmetric (linspace(-3, 3, 64): d[63-i] = -d[i]), so
+// k(-a - d[i]) = k(a - d[63-i]).  Three kernel rows per pixel serve all six:
+//     H_R[i][j] = sum Iy ka[i]    kb[j]        H_G[i][j] = sum Iy ka[63-i] kc[j]        H_B[i][j] = sum Iy kb[63-i] kc[63-j]
+// grid = (image, pixel range): each workgroup contracts its range of pixels -- or of the image's colour points (weights =
+// pixel counts) -- and writes one partial [3][64][64]; rgbuv_hist_fold_kernel adds the ranges in order.
+#define H3_PB 48
+#define H3_PS 3
+template <typename T>
+__global__ __launch_bounds__(256) void rgbuv_hist_fwd3_kernel(int H, int W, TView img, const f32x4* __restrict__ points,
+                                                             const int* __restrict__ npoints, int cap, float* __restrict__ part) {
+    __shared__ float Aa[H3_PB][HB], Ab[H3_PB][HB];      // Iy*w*ka, Iy*w*kb   (row operands)
+    __shared__ float Bb[H3_PB][HB], Bc[H3_PB][HB];      // kb, kc             (column operands)
+    __shared__ float sa[H3_PB], sb[H3_PB], sc[H3_PB], siy[H3_PB];
+    const int n = blockIdx.x, ps = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ti = wave >> 1, tj = wave & 1;
+    const int HW = H * W;
+    const int np = (points && npoints) ? npoints[n] : -1;
+    const bool listed = np >= 0;
+    const int total = listed ? np : HW;
+    int chunk = (total + H3_PS - 1) / H3_PS;
+    chunk = (chunk + H3_PB - 1) / H3_PB * H3_PB;
+    const int q0 = ps * chunk, q1 = min(total, q0 + chunk);
+    f32x16 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+    for (int p0 = q0; p0 < q1; p0 += H3_PB) {
+        if (tid < H3_PB) {
+            const int p = p0 + tid;
+            float a = 0.f, b = 0.f, c = 0.f, iy = 0.f;
+            if (p < q1) {
+                float x[3], wgt = 1.f;
+                if (listed) {
+                    const f32x4 e = points[(long long)n * cap + p];
+                    x[0] = e[0] * 0.5f + 0.5f; x[1] = e[1] * 0.5f + 0.5f; x[2] = e[2] * 0.5f + 0.5f;
+                    wgt = e[3];
+                } else {
+                    load_rgb01<T>(img, n, p, W, x);
+                }
+                iy = wgt * sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + HIST_EPS);
+                const float lr = logf(x[0] + HIST_EPS), lg = logf(x[1] + HIST_EPS), lb = logf(x[2] + HIST_EPS);
+                a = lr - lg; b = lr - lb; c = lg - lb;
+            }
+            sa[tid] = a; sb[tid] = b; sc[tid] = c; siy[tid] = iy;       // iy = 0 beyond the range: contributes nothing
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H3_PB * HB; idx += 256) {
+            const int p = idx >> 6, i = idx & 63;
+            const float d = hist_center(i), iy = siy[p];
+            const float ka = iq_kernel(sa[p] - d), kb = iq_kernel(sb[p] - d), kc = iq_kernel(sc[p] - d);
+            Aa[p][i] = iy * ka; Ab[p][i] = iy * kb; Bb[p][i] = kb; Bc[p][i] = kc;
+        }
+        __syncthreads();
+        const int ci = ti * 32 + (lane & 31), cj = tj * 32 + (lane & 31);
+#pragma unroll 4
+        for (int kk = 0; kk < H3_PB / 2; ++kk) {
+            const int row = 2 * kk + (lane >> 5);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aa[row][ci], Bb[row][cj], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aa[row][63 - ci], Bc[row][cj], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[row][63 - ci], Bc[row][63 - cj], acc[2], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* out = part + ((long long)n * H3_PS + ps) * 3 * HB * HB;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int j = tj * 32 + (lane & 31);
+            out[(c * HB + i) * HB + j] = acc[c][e];
+        }
+}
+
+__global__ __launch_bounds__(256) void rgbuv_hist_fold_kernel(const float* __restrict__ part, float* __restrict__ hist) {
+    const int n = blockIdx.x;
+    const int E = 3 * HB * HB;
+    const f32x4* src = (const f32x4*)(part + (long long)n * H3_PS * E);
+    f32x4* dst = (f32x4*)(hist + (long long)n * E);
+    for (int i = threadIdx.x; i < E / 4; i += 256) {
+        f32x4 s = src[i];
+#pragma unroll
+        for (int k = 1; k < H3_PS; ++k) s += src[k * (E / 4) + i];
+        dst[i] = s;
+    }
+}
+
 // ---- per-image totals, Hellinger partial sum and dL/d(raw histogram) ---------------------------------------
 // totals[n] = sum_{c,i,j} raw[n]  (histogram.py:78);  sq_part[n] = sum (sqrt(p/Tp) - sqrt(q/Tq))^2 of image n (histogram.py:88-89);
 // hellinger_sq_sum_kernel adds the images in index order (deterministic: no float atomics)
@@ -281,6 +460,29 @@ extern "C" int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tens
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && img && img->ptr && hist, "p2p_rgbuv_hist_fwd: bad args");
     P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd_kernel<T><<<dim3(N, 3), 256, 0, (hipStream_t)stream>>>(H, W, make_view(img), hist)));
     return p2p_check_launch("p2p_rgbuv_hist_fwd");
+}
+
+extern "C" long long p2p_rgbuv_hist_fwd3_workspace_bytes(int N) { return (long long)N * H3_PS * 3 * HB * HB * (long long)sizeof(float); }
+
+extern "C" int p2p_rgbuv_points(int dtype, int N, int H, int W, const p2p_tensor* img, int cap, float* points, int* npoints, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && img && img->ptr && points && npoints && cap > 0, "p2p_rgbuv_points: bad args");
+    P2P_REQUIRE(((uintptr_t)points % 16) == 0, "p2p_rgbuv_points: the point list must be 16-byte aligned");
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_points_kernel<T><<<dim3(N), 256, 0, (hipStream_t)stream>>>(H, W, make_view(img), cap, (f32x4*)points, npoints)));
+    return p2p_check_launch("p2p_rgbuv_points");
+}
+
+extern "C" int p2p_rgbuv_hist_fwd3(int dtype, int N, int H, int W, const p2p_tensor* img, const float* points, const int* npoints,
+                                   int cap, float* hist, float* workspace, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && img && img->ptr && hist && workspace, "p2p_rgbuv_hist_fwd3: bad args");
+    P2P_REQUIRE((points == nullptr) == (npoints == nullptr), "p2p_rgbuv_hist_fwd3: points and npoints come together");
+    P2P_REQUIRE(((uintptr_t)workspace % 16) == 0 && ((uintptr_t)hist % 16) == 0, "p2p_rgbuv_hist_fwd3: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd3_kernel<T><<<dim3(N, H3_PS), 256, 0, st>>>(H, W, make_view(img), (const f32x4*)points,
+                                                                                        npoints, cap, workspace)));
+    int rc = p2p_check_launch("p2p_rgbuv_hist_fwd3");
+    if (rc) return rc;
+    rgbuv_hist_fold_kernel<<<dim3(N), 256, 0, st>>>(workspace, hist);
+    return p2p_check_launch("p2p_rgbuv_hist_fwd3 fold");
 }
 
 extern "C" int p2p_hellinger_fwd(const float* hist_true, const float* hist_pred, int N, float* tot_true, float* tot_pred,

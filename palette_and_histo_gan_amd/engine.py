@@ -274,6 +274,8 @@ class Pix2PixEngine:
         self._prep_table = {}
         self._head_prepped = False
         self.fuse_act_bwd = int(os.environ.get("P2P_FUSE_ACT_BWD", "1"))   # D.last data gradient + LeakyReLU backward in one launch
+        self.hist_fwd3 = int(os.environ.get("P2P_HIST_FWD3", "1"))      # three shared kernel rows per pixel, all components in one workgroup
+        self.hist_points = int(os.environ.get("P2P_HIST_POINTS", "1"))  # real image: contraction over its distinct colours
         self.split_prep = int(os.environ.get("P2P_SPLIT_PREP", "1"))    # weight copies of the early-Adam part refreshed right behind it
         self.refresh_weight_copies()
 
@@ -1031,7 +1033,7 @@ class Pix2PixEngine:
         fake_view = L.Tensor(P["fake32"].data_ptr(), S * S, S, 4)
         assert P.get("h_real_done"), "the real histogram is taken by _hist_real_early"
         P["h_real_done"] = False
-        L.call("p2p_rgbuv_hist_fwd", L.F32, B, S, S, C.byref(fake_view), _p(P["h_fake"]), _stream())
+        self._hist_fwd(P, B, fake_view, P["h_fake"], points=False)
         L.call("p2p_hellinger_fwd", _p(P["h_real"]), _p(P["h_fake"]), B, _p(P["h_tot"][0]), _p(P["h_tot"][1]),
                _p(P["h_sqp"]), _p(P["h_sq"]), _stream())
         if hist_allreduce is not None:
@@ -1055,6 +1057,9 @@ class Pix2PixEngine:
         P["h_sq"] = torch.zeros(4, dtype=torch.float32, device=dev)
         P["h_sqp"] = torch.zeros(B, dtype=torch.float32, device=dev)      # per-image partials of the Hellinger sum
         P["h_dimg"] = torch.empty(3 * B * S * S * 4, dtype=torch.float32, device=dev)
+        P["h_ws"] = torch.empty(L.lib().p2p_rgbuv_hist_fwd3_workspace_bytes(B) // 4, dtype=torch.float32, device=dev)
+        P["h_points"] = torch.empty((B, self.HIST_POINT_CAP, 4), dtype=torch.float32, device=dev)
+        P["h_npoints"] = torch.zeros(B, dtype=torch.int32, device=dev)
         P["fake32"] = torch.empty(B * S * S * 4, dtype=torch.float32, device=dev)      # tanh output before rounding to the activation dtype
 
     def _hist_real_early(self, P, B, real_t):
@@ -1065,8 +1070,23 @@ class Pix2PixEngine:
         P["h_real_src"] = real_t           # keep the batch tensor alive until the kernel has run
         self.side_hist.fork()
         with self.side_hist.run():
-            L.call("p2p_rgbuv_hist_fwd", L.F32, B, S, S, C.byref(L.Tensor(real_t.data_ptr(), S * S, S, 4)), _p(P["h_real"]), _stream())
+            self._hist_fwd(P, B, L.Tensor(real_t.data_ptr(), S * S, S, 4), P["h_real"], points=True)
         P["h_real_done"] = True
+
+    HIST_POINT_CAP = 1024        # colour points kept per image; an image with more is contracted over its pixels
+
+    def _hist_fwd(self, P, B, view, out, points):
+        """raw RGB-uv histograms [B][3][64][64] of a dense f32 image view (histogram.py:35-81 up to the normalisation).
+        points=True: the image is a palette sprite (the REAL image of a step) -- contract over its distinct colours."""
+        S = self.S
+        if not self.hist_fwd3:
+            L.call("p2p_rgbuv_hist_fwd", L.F32, B, S, S, C.byref(view), _p(out), _stream())
+            return
+        pts = npts = NULL
+        if points and self.hist_points:
+            L.call("p2p_rgbuv_points", L.F32, B, S, S, C.byref(view), self.HIST_POINT_CAP, _p(P["h_points"]), _p(P["h_npoints"]), _stream())
+            pts, npts = _p(P["h_points"]), _p(P["h_npoints"])
+        L.call("p2p_rgbuv_hist_fwd3", L.F32, B, S, S, C.byref(view), pts, npts, self.HIST_POINT_CAP, _p(out), _p(P["h_ws"]), _stream())
 
     def rgbuv_histogram(self, image):
         """histogram.calculate_rgbuv_histogram (histogram.py:35-81) of a dense f32 (B,S,S,4) batch in [-1,1]:

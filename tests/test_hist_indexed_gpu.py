@@ -49,6 +49,60 @@ def test_histogram_tail_batches_small_image():
     assert U.rel_err(out.cpu().numpy(), ref) < 1e-4
 
 
+def _fwd3(img, points, cap=1024):
+    """p2p_rgbuv_hist_fwd3 (+ p2p_rgbuv_points) on a dense f32 (N,S,S,4) batch -> normalised (N,64,64,3), npoints"""
+    N, S = img.shape[0], img.shape[1]
+    t = U.dev(img)
+    view = L.Tensor(t.data_ptr(), S * S, S, 4)
+    raw = torch.empty(N * 3 * 64 * 64, dtype=torch.float32, device=U.DEV)
+    ws = torch.empty(L.lib().p2p_rgbuv_hist_fwd3_workspace_bytes(N) // 4, dtype=torch.float32, device=U.DEV)
+    pts = torch.full((N, cap, 4), float("nan"), dtype=torch.float32, device=U.DEV)
+    npts = torch.full((N,), -7, dtype=torch.int32, device=U.DEV)
+    if points:
+        L.call("p2p_rgbuv_points", L.F32, N, S, S, C.byref(view), cap, U.ptr(pts), U.ptr(npts), U.stream())
+    L.call("p2p_rgbuv_hist_fwd3", L.F32, N, S, S, C.byref(view), U.ptr(pts) if points else None, U.ptr(npts) if points else None,
+           cap, U.ptr(raw), U.ptr(ws), U.stream())
+    out = torch.empty((N, 64, 64, 3), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_hist_normalize", U.ptr(raw), N, U.ptr(out), U.stream())
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), npts.cpu().numpy(), pts.cpu().numpy()
+
+
+@pytest.mark.parametrize("S", [8, 64, 128])
+def test_shared_row_histogram_and_colour_points_match_the_oracle(S):
+    """p2p_rgbuv_hist_fwd3: three kernel rows per pixel serve all three components (mirrored bin grid); p2p_rgbuv_points:
+    contraction over distinct colours x pixel counts.  Both against the f64 oracle at 1e-4, and against each other."""
+    rng = np.random.default_rng(34)
+    _, tgt = rg.synthetic_rgba_batch(rng, 3, max(S, 64), palette_size=24)
+    tgt = tgt[:, :S, :S].copy()
+    noisy = np.clip(tgt + rng.normal(scale=0.1, size=tgt.shape), -1, 1).astype(np.float32)     # every pixel its own colour
+    ref_t = rg.rgbuv_histogram(torch.tensor(tgt, dtype=F64)).numpy()
+    ref_n = rg.rgbuv_histogram(torch.tensor(noisy, dtype=F64)).numpy()
+    dense_t, _, _ = _fwd3(tgt, points=False)
+    dense_n, _, _ = _fwd3(noisy, points=False)
+    assert U.rel_err(dense_t, ref_t) < 1e-4 and U.rel_err(dense_n, ref_n) < 1e-4
+    listed_t, npts, pts = _fwd3(tgt, points=True)
+    assert U.rel_err(listed_t, ref_t) < 1e-4
+    assert np.abs(listed_t - dense_t).max() <= 2e-6 * dense_t.max()            # same numbers up to f32 summation order
+    tiles = (S * S + 1023) // 1024
+    for n in range(3):
+        k = int(npts[n])
+        colours = len(np.unique(tgt[n].reshape(-1, 4)[:, :3], axis=0))
+        assert colours <= k <= colours * tiles                                  # distinct per tile of 1024 pixels, tiles not merged
+        assert pts[n, :k, 3].sum() == S * S and (pts[n, :k, 3] >= 1).all()      # the counts cover every pixel once
+        assert len(np.unique(pts[n, :k, :3], axis=0)) == colours
+    # an image with more colours than the list holds is contracted densely (npoints = -1), with the same result
+    listed_n, npts_n, _ = _fwd3(noisy, points=True, cap=64)
+    if S >= 64:
+        assert (npts_n == -1).all()
+    assert np.abs(listed_n - dense_n).max() <= 2e-6 * dense_n.max()
+    # determinism: the list is a function of the image alone
+    again = _fwd3(tgt, points=True)
+    assert np.array_equal(again[1], npts) and np.array_equal(again[0], listed_t)
+    for n in range(3):
+        assert np.array_equal(again[2][n, :npts[n]], pts[n, :npts[n]])
+
+
 @pytest.mark.parametrize("size", [8, 64])
 def test_hellinger_loss_and_gradient_match_closed_form(size):
     rng = np.random.default_rng(33)

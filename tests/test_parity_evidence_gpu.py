@@ -97,9 +97,14 @@ def test_c5_shape_histogram_model_128x128_against_the_f64_oracle():
     want = np.array([g_ref[0], g_ref[1], g_ref[2], g_ref[3], d_ref[0], d_ref[1], d_ref[2]])
     err = np.abs(out - want) / np.abs(want)
     eng_g = _per_tensor_l2(eng.G.export(eng.G.grads), ref["g_grads"])
-    _record("c5_shape_hist_B8_S128_f32_vs_f64_oracle", {"loss_rel_err": err.tolist(), "engine_grad_l2": eng_g})
+    f32 = lambda p: {k: v.to(torch.float32) for k, v in p.items()}
+    ref32 = rg.train_step_rgba(f32(Gp), f32(Dp), torch.tensor(src), torch.tensor(tgt), [m.to(torch.float32) for m in tm],
+                               lambda_l1=30.0, lambda_hist=1.0)
+    ora_g = _per_tensor_l2({k: v.numpy() for k, v in ref32["g_grads"].items()}, ref["g_grads"])
+    _record("c5_shape_hist_B8_S128_f32_vs_f64_oracle", {"loss_rel_err": err.tolist(), "engine_grad_l2": eng_g, "oracle_f32_grad_l2": ora_g})
     assert err.max() <= 1e-4, err
-    assert max(eng_g.values()) <= 2e-3, max(eng_g.items(), key=lambda kv: kv[1])       # as the 64x64 histogram test
+    for k, e in eng_g.items():       # yardstick as in the c2 test: the f32 oracle's own error on the same tensor (measured: both ~2e-3)
+        assert e <= max(1e-3, 4.0 * ora_g.get(k, 0.0)), (k, e, ora_g.get(k))
 
 
 @pytest.mark.timeout(900)
