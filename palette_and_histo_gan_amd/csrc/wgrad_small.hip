@@ -314,7 +314,7 @@ struct WsPlan { int ok, GT, DT, gwins, dwins, TH, blocks, pack, nbuf, buf_bytes,
 static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int Cd, int hi_ld, int lo_ld) {
     WsPlan p = {};
     const int esz = dtype == P2P_BF16 ? 2 : 4;
-    if ((LW & (LW - 1)) || LW < 16 || LW > 64) return p;
+    if ((LW & (LW - 1)) || LW < 16 || LW > 128) return p;       // 128: the stride-1 heads of 128x128 sprites (c5), strips of 4 rows
     if ((hi_ld * esz) % 16 || (lo_ld * esz) % 16) return p;
     const int gt_all = (Cg + 31) / 32, dt_all = (Cd + 31) / 32;
     // windows: at most 2 tiles along g, then as many along d as keep GT*DT <= 4

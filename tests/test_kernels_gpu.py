@@ -621,7 +621,7 @@ def test_fused_block_conv_instance_norm_activation(op, n, lh, cg, cd, act, cbw, 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,stride", [(3, 32, 4, 64, 2), (2, 32, 8, 64, 2), (2, 64, 36, 4, 1), (3, 32, 64, 1, 1),
                                                 (2, 16, 1, 64, 2), (20, 64, 33, 8, 1), (3, 32, 32, 128, 2), (2, 16, 64, 128, 2),
-                                                (2, 16, 64, 256, 2), (2, 32, 64, 64, 2)])
+                                                (2, 16, 64, 256, 2), (2, 32, 64, 64, 2), (2, 128, 36, 4, 1), (2, 128, 64, 1, 1)])
 def test_wgrad_small_lds_resident(dtype, n, lh, cg, cd, stride):
     """Edge-layer weight gradients through the LDS-resident kernel (all 16 taps out of one staged strip)."""
     rng = np.random.default_rng(18)
