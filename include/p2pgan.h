@@ -307,6 +307,20 @@ int p2p_softmax_cce_argmax(int dtype, int N, int H, int W, int C, const p2p_tens
 /* tf.argmax(probs, axis=-1, output_type=int32) on dense f32 probabilities [M][C]; ties -> lowest index. */
 int p2p_argmax_lastdim(const float* probs, long long M, int C, int* out, void* stream);
 
+/* The palette-index head in one launch (bf16, IMG_SIZE 64: query p2p_head_softmax_ok): Conv2D(256, 4, stride 1, SAME, bias) of
+ * the haloed concat view `in` (pixels of cin_pad = 40 channels: [up6 32 | source | zero pad], networks.py:75-78,92-94) with
+ * the op-G weight copy wt[16][256][40], softmax over the 256 palette slots, argmax (ties -> lowest index) written as an
+ * activation-dtype value into `fake_idx`, CategoricalCrossentropy against the index image `target` in the log-sum-exp form,
+ * and its gradient grad_scale * (probs - onehot) into the haloed view `dz` (256-channel pixels) -- what p2p_igemm_edge +
+ * p2p_softmax_cce_argmax + p2p_view_colsum compute, without ever writing the logits (pix2pix_model.py:268,273-293,300-301).
+ * loss_out[0] = inv_count * sum of -log p_target, loss_out[1] = inv_count / 256 * sum |onehot - p|; dbias (may be NULL) =
+ * column sums of dz.  workspace: p2p_head_softmax_workspace_bytes(N, H) bytes (per-workgroup partials, summed in order). */
+int p2p_head_softmax_ok(int dtype, int N, int H, int W, int cin_pad, int ncls);
+long long p2p_head_softmax_workspace_bytes(int N, int H);
+int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad, int ncls, const p2p_tensor* in, const void* wt,
+                         const float* bias, const p2p_tensor* target, const p2p_tensor* fake_idx, float grad_scale,
+                         float inv_count, const p2p_tensor* dz, float* dbias, float* workspace, float* loss_out, void* stream);
+
 /* ---- optimizer / parameter plumbing (pix2pix_model.py:28-29,81-83) ------------------------------- */
 
 /* Keras Adam over a flat f32 buffer; t = iteration AFTER increment; grads are multiplied by gscale first. */

@@ -1,0 +1,320 @@
+// Palette-index head of Pix2PixIndexedModel in ONE kernel (pix2pix_model.py:261-325 over networks.py:75-78):
+//     z[p][c]   = bias[c] + sum_{kh,kw,g} c6[p + (kh-1, kw-1)][g] * W[kh][kw][g][c]        Conv2D(256, 4, stride 1, SAME, bias)
+//     probs     = softmax(z)            fake index = argmax(probs), ties -> lowest index     (:268, :286, :292)
+//     seg       = mean_p -log probs[target]                                                  (:265, :274; log-sum-exp form)
+//     dz[p][c]  = lambda_seg / #pixels * (probs - onehot(target))                            (the only gradient G receives, :263)
+//     dbias     = per-workgroup column sums of dz (summed in fixed order by head_bias_sum_kernel)
+// The 256-channel logits (268 MB at B = 128 in bf16) are never written: the generic path wrote them, read them back in
+// p2p_softmax_cce_argmax and read dz a third time for the bias gradient (SURVEY.md 2.3 K13/K14 "fuse, never materialise").
+//
+// bf16, IMG_SIZE 64.  One workgroup (8 waves) owns 4 output rows x 64 pixels x all 256 channels:
+//   * MFMA rows = channels, columns = pixels, so a lane holds 4 x 16 channels of ONE pixel per column tile and the softmax
+//     reductions over channels are in-lane loops + one exchange with lane^32 + one with the partner wave (other channel half);
+//   * the 7 x 67 pixel input strip (80-byte pixels: [up6 32 | source | zero pad]) is staged in LDS once; the four taps of a
+//     kernel row are CONTIGUOUS there (pixel x-1+kw, channel g  <->  byte x*80 + 2*(40 kw + g)), so K runs over 160 values
+//     per kernel row in 10 steps of 16 with no tap bookkeeping and no padding beyond the 40-channel pixels;
+//   * the weights (327 KB) stream through a ring of 40 KB LDS stages (half a kernel row each) in MFMA-fragment order
+//     (LDS-DMA with per-lane source addresses: lane (i, h) of block (step, channel tile) fetches its own 16 bytes), counted
+//     s_waitcnt vmcnt + one raw s_barrier per stage;
+//   * epilogue: softmax / CCE / argmax / gradient in registers, the bf16 gradient tile is transposed through LDS (padded
+//     528-byte pixels) and leaves as whole 512-byte pixels.
+#include "p2p_common.hpp"
+
+#define HS_W 64
+#define HS_ROWS 4
+#define HS_CIN 40
+#define HS_NCLS 256
+#define HS_PIXB (HS_CIN * 2)                         // 80 bytes per input pixel
+#define HS_STRIP_COLS (HS_W + 3)
+#define HS_STRIP_ROWB (HS_STRIP_COLS * HS_PIXB)      // 5360
+#define HS_STRIP_ROWS (HS_ROWS + 3)
+#define HS_STRIP_BYTES (HS_STRIP_ROWS * HS_STRIP_ROWB)   // 37520
+#define HS_STAGE_STEPS 5
+#define HS_STAGE_BYTES (HS_STAGE_STEPS * 8 * 1024)   // 40 KB: 5 K steps x 8 channel tiles x 64 lanes x 16 B
+#define HS_NSTAGE 8                                  // 4 kernel rows x 2 halves
+#define HS_RING 3
+#define HS_PATCH_PIXB 528                            // 512-byte gradient pixel + 16 bytes: conflict-free ds_write_b64 / ds_read_b128
+
+struct HsArgs {
+    const char* in; long long in_img; int in_row;     // c6 view (element strides, ld = HS_CIN)
+    const char* wt;                                   // [16][256][40] bf16
+    const float* bias;
+    const bf16_t* target; long long tg_img; int tg_row; int tg_ld;
+    bf16_t* fake; long long fk_img; int fk_row; int fk_ld;
+    char* dz; long long dz_img; int dz_row;           // ld = 256
+    float* dbias_part;                                // [nwg][256] or null
+    float* loss_part;                                 // [2][nwg]
+    float grad_scale, inv_count;
+    int H;
+};
+
+__device__ __forceinline__ void hs_glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* strip = smem;
+    char* ring = smem + ((HS_STRIP_BYTES + 255) & ~255);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, pr = wave >> 1;            // channel half, output row of the tile
+    const int h = lane >> 5, li = lane & 31;
+    const int tiles_per_img = a.H / HS_ROWS;
+    const int n = blockIdx.x / tiles_per_img, y0 = (blockIdx.x % tiles_per_img) * HS_ROWS;
+
+    // ---- staging ---------------------------------------------------------------------------------------------------
+    {   // input strip: rows y0-1 .. y0+5, columns -1 .. 65, each row 5360 contiguous bytes in HBM
+        constexpr int CPR = HS_STRIP_ROWB / 16, TOTAL = HS_STRIP_ROWS * CPR;      // 335 chunks per row
+        const char* base = a.in + ((long long)n * a.in_img + (long long)(y0 - 1) * a.in_row - 1) * HS_PIXB;
+        for (int c0 = wave * 64; c0 < TOTAL; c0 += 512) {
+            const int ci = c0 + lane;
+            if (ci < TOTAL) {
+                const int r = ci / CPR, cc = ci - r * CPR;
+                hs_glds16(base + (long long)r * a.in_row * HS_PIXB + cc * 16, strip + c0 * 16);
+            }
+        }
+    }
+    // weight stage st = (kh, half): block (s, ct) = 1 KB in fragment order; wave w stages channel tile ct = w of every step
+    auto stage_w = [&](int st, char* buf) {
+        const int kh = st >> 1, s0 = (st & 1) * HS_STAGE_STEPS;
+#pragma unroll
+        for (int s = 0; s < HS_STAGE_STEPS; ++s) {
+            const int kp = 16 * (s0 + s) + 8 * h;              // k' of this lane's 8 values inside the kernel row (0..159)
+            const int kw = kp / HS_CIN, c = kp - kw * HS_CIN;
+            const char* src = a.wt + ((((long long)(kh * 4 + kw)) * HS_NCLS + wave * 32 + li) * HS_CIN + c) * 2;
+            hs_glds16(src, buf + (s * 8 + wave) * 1024);
+        }
+    };
+    stage_w(0, ring);
+    stage_w(1, ring + HS_STAGE_BYTES);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- main loop: 8 stages x 5 K steps x (4 channel tiles x 2 pixel tiles) ------------------------------------------
+#pragma unroll 1
+    for (int st = 0; st < HS_NSTAGE; ++st) {
+        if (st + 1 < HS_NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HS_STAGE_STEPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < HS_NSTAGE) stage_w(st + 2, ring + ((st + 2) % HS_RING) * HS_STAGE_BYTES);
+        const char* wbuf = ring + (st % HS_RING) * HS_STAGE_BYTES;
+        const int kh = st >> 1, s0 = (st & 1) * HS_STAGE_STEPS;
+        const char* brow = strip + (pr + kh) * HS_STRIP_ROWB + li * HS_PIXB + 16 * h;
+#pragma unroll
+        for (int s = 0; s < HS_STAGE_STEPS; ++s) {
+            bf16x8 bfr[2], afr[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(brow + j * 32 * HS_PIXB + 32 * (s0 + s));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) afr[i] = *(const bf16x8*)(wbuf + (s * 8 + cw * 4 + i) * 1024 + lane * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();          // every wave is done with the strip and the ring: both are re-used below
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    // LDS: gradient patch [256 pixels][528 B] from offset 0; exchange arrays behind it
+    char* patch = smem;
+    float* xch = (float*)(smem + 256 * HS_PATCH_PIXB);        // [5][2 halves][256 pixels]
+    constexpr int XS = 2 * 256;
+    float* xmax = xch, *xsum = xch + XS, *xzt = xch + 2 * XS, *xbest = xch + 3 * XS, *xpt = xch + 4 * XS;
+    int* xbidx = (int*)(xch + 5 * XS);
+    float* sbias = xch + 6 * XS;                               // [256]
+    float* spix = sbias + 256;                                 // [2][256]: per-pixel loss terms
+    if (tid < HS_NCLS) sbias[tid] = a.bias ? a.bias[tid] : 0.f;
+    __syncthreads();
+    const int chbase = cw * 128 + 4 * h;       // channel of (i, e): chbase + 32 i + (e & 3) + 8 (e >> 2)
+    int tix[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = j * 32 + li, y = y0 + pr;
+        tix[j] = (int)to_f32(a.target[((long long)n * a.tg_img + (long long)y * a.tg_row + x) * a.tg_ld]);
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] += sbias[chbase + 32 * i + (e & 3) + 8 * (e >> 2)];
+                m = fmaxf(m, acc[i][j][e]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (h == 0) xmax[cw * 256 + pr * 64 + x] = m;
+    }
+    __syncthreads();
+    float S[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int px = pr * 64 + j * 32 + li;
+        const float M = fmaxf(xmax[px], xmax[256 + px]);
+        float s = 0.f, zt = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = acc[i][j][e] - M;
+                if (chbase + 32 * i + (e & 3) + 8 * (e >> 2) == tix[j]) zt = d;      // z_t - max, before the exponential
+                const float ex = expf(d);
+                acc[i][j][e] = ex;
+                s += ex;
+            }
+        s += __shfl_xor(s, 32, 64);
+        zt += __shfl_xor(zt, 32, 64);
+        if (h == 0) { xsum[cw * 256 + px] = s; xzt[cw * 256 + px] = zt; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int px = pr * 64 + j * 32 + li;
+        S[j] = xsum[px] + xsum[256 + px];
+        float best = -1.f, pt = 0.f;
+        int bidx = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ch = chbase + 32 * i + (e & 3) + 8 * (e >> 2);
+                const float p = acc[i][j][e] / S[j];           // probabilities as tf.nn.softmax forms them: exp(z - max) / sum
+                if (p > best) { best = p; bidx = ch; }         // channels ascend with (i, e): strict '>' keeps the lowest index
+                if (ch == tix[j]) pt = p;
+                acc[i][j][e] = (p - (ch == tix[j] ? 1.f : 0.f)) * a.grad_scale;
+            }
+        {
+            const float ob = __shfl_xor(best, 32, 64);
+            const int oi = __shfl_xor(bidx, 32, 64);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            pt += __shfl_xor(pt, 32, 64);
+        }
+        if (h == 0) { xbest[cw * 256 + px] = best; xbidx[cw * 256 + px] = bidx; xpt[cw * 256 + px] = pt; }
+        // gradient tile -> LDS patch [pixel][channel] in bf16, 4 consecutive channels per store
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef __attribute__((__vector_size__(4 * sizeof(bf16_t)))) bf16_t bf16x4;
+                bf16x4 v4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v4[k] = (bf16_t)acc[i][j][4 * g + k];
+                *(bf16x4*)(patch + px * HS_PATCH_PIXB + (chbase + 32 * i + 8 * g) * 2) = v4;
+            }
+    }
+    __syncthreads();
+    // argmax across the channel halves, loss terms, fake index: one thread per pixel
+    if (tid < 256) {
+        const int px = tid, r = px >> 6, x = px & 63, y = y0 + r;
+        float b0 = xbest[px], b1 = xbest[256 + px];
+        int i0 = xbidx[px], i1 = xbidx[256 + px];
+        if (b1 > b0 || (b1 == b0 && i1 < i0)) { b0 = b1; i0 = i1; }
+        a.fake[((long long)n * a.fk_img + (long long)y * a.fk_row + x) * a.fk_ld] = (bf16_t)(float)i0;
+        const float pt = xpt[px] + xpt[256 + px];
+        // per-pixel terms need S and z_t - max of THIS pixel: recomputed from the exchange arrays
+        spix[px] = logf(xsum[px] + xsum[256 + px]) - (xzt[px] + xzt[256 + px]);
+        spix[256 + px] = 2.f * (1.f - pt);           // sum_c |onehot_c - p_c| = (1 - p_t) + sum_{c != t} p_c
+    }
+    // whole 512-byte gradient pixels: 32 lanes x 16 B per pixel
+    {
+        const int sub = tid & 31;
+        for (int px = tid >> 5; px < 256; px += 16) {
+            const int r = px >> 6, x = px & 63, y = y0 + r;
+            const f32x4 v = *(const f32x4*)(patch + px * HS_PATCH_PIXB + sub * 16);
+            *(f32x4*)(a.dz + ((long long)n * a.dz_img + (long long)y * a.dz_row + x) * (HS_NCLS * 2) + sub * 16) = v;
+        }
+    }
+    // bias gradient partial: column sums of the ROUNDED gradient tile, pixels in order
+    if (a.dbias_part && tid < HS_NCLS) {
+        float s = 0.f;
+        for (int px = 0; px < 256; ++px) s += to_f32(*(const bf16_t*)(patch + px * HS_PATCH_PIXB + tid * 2));
+        a.dbias_part[(long long)blockIdx.x * HS_NCLS + tid] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {           // fixed-order sums of the 256 per-pixel loss terms
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = 0; k < 4; ++k) { s0 += spix[tid + 64 * k]; s1 += spix[256 + tid + 64 * k]; }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (tid == 0) {
+            a.loss_part[blockIdx.x] = s0 * a.inv_count;
+            a.loss_part[gridDim.x + blockIdx.x] = s1 * a.inv_count / (float)HS_NCLS;
+        }
+    }
+}
+
+// loss_out[k] = sum_b part[k][b]; dbias[c] = sum_b dbias_part[b][c] -- workgroup order, bit-reproducible
+__global__ __launch_bounds__(256) void head_loss_sum_kernel(const float* __restrict__ part, int nb, float* __restrict__ loss_out) {
+    __shared__ float red[16];
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < nb; b += 256) s += part[k * nb + b];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) loss_out[k] = s;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bias_sum_kernel(const float* __restrict__ part, int nb, float* __restrict__ dbias) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 256) s += part[(long long)b * HS_NCLS + c];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) dbias[c] = s;
+}
+
+extern "C" int p2p_head_softmax_ok(int dtype, int N, int H, int W, int cin_pad, int ncls) {
+    return dtype == P2P_BF16 && N > 0 && W == HS_W && H % HS_ROWS == 0 && cin_pad == HS_CIN && ncls == HS_NCLS;
+}
+
+extern "C" long long p2p_head_softmax_workspace_bytes(int N, int H) {
+    const long long nwg = (long long)N * (H / HS_ROWS);
+    return nwg * (HS_NCLS + 2) * (long long)sizeof(float);
+}
+
+extern "C" int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad, int ncls, const p2p_tensor* in, const void* wt,
+                                    const float* bias, const p2p_tensor* target, const p2p_tensor* fake_idx, float grad_scale,
+                                    float inv_count, const p2p_tensor* dz, float* dbias, float* workspace, float* loss_out,
+                                    void* stream) {
+    P2P_REQUIRE(p2p_head_softmax_ok(dtype, N, H, W, cin_pad, ncls), "p2p_head_softmax_cce: shape not supported (query p2p_head_softmax_ok)");
+    P2P_REQUIRE(in && in->ptr && wt && target && target->ptr && fake_idx && fake_idx->ptr && dz && dz->ptr && workspace && loss_out,
+                "p2p_head_softmax_cce: null pointer");
+    P2P_REQUIRE(in->ld == HS_CIN && dz->ld == HS_NCLS, "p2p_head_softmax_cce: input pixels hold %d channels, gradient pixels %d", HS_CIN, HS_NCLS);
+    P2P_REQUIRE(((uintptr_t)in->ptr % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)dz->ptr % 16) == 0, "p2p_head_softmax_cce: alignment");
+    HsArgs a;
+    a.in = (const char*)in->ptr; a.in_img = in->img_stride; a.in_row = in->row_stride;
+    a.wt = (const char*)wt; a.bias = bias;
+    a.target = (const bf16_t*)target->ptr; a.tg_img = target->img_stride; a.tg_row = target->row_stride; a.tg_ld = target->ld;
+    a.fake = (bf16_t*)fake_idx->ptr; a.fk_img = fake_idx->img_stride; a.fk_row = fake_idx->row_stride; a.fk_ld = fake_idx->ld;
+    a.dz = (char*)dz->ptr; a.dz_img = dz->img_stride; a.dz_row = dz->row_stride;
+    const int nwg = N * (H / HS_ROWS);
+    a.loss_part = workspace;
+    a.dbias_part = dbias ? workspace + 2 * (long long)nwg : nullptr;
+    a.grad_scale = grad_scale; a.inv_count = inv_count; a.H = H;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int SHM_EPI = 256 * HS_PATCH_PIXB + (6 * 512 + 256 + 512) * 4;                       // gradient patch + exchange arrays
+    constexpr int SHM_MAIN = ((HS_STRIP_BYTES + 255) & ~255) + HS_RING * HS_STAGE_BYTES;          // input strip + weight ring
+    constexpr int SHM = SHM_EPI > SHM_MAIN ? SHM_EPI : SHM_MAIN;
+    static_assert(SHM <= 160 * 1024, "LDS budget");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)head_softmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        attr = true;
+    }
+    head_softmax_kernel<<<dim3(nwg), dim3(512), SHM, st>>>(a);
+    int rc = p2p_check_launch("p2p_head_softmax_cce");
+    if (rc) return rc;
+    head_loss_sum_kernel<<<1, 256, 0, st>>>(a.loss_part, nwg, loss_out);
+    if (dbias) head_bias_sum_kernel<<<dim3(HS_NCLS), 256, 0, st>>>(a.dbias_part, nwg, dbias);
+    return p2p_check_launch("p2p_head_softmax_cce sums");
+}

@@ -274,6 +274,7 @@ class Pix2PixEngine:
         self._prep_table = {}
         self._head_prepped = False
         self.fuse_act_bwd = int(os.environ.get("P2P_FUSE_ACT_BWD", "1"))   # D.last data gradient + LeakyReLU backward in one launch
+        self.use_head_fused = os.environ.get("P2P_HEAD_FUSED", "1") != "0"    # indexed head: conv + softmax + CCE + argmax + gradient in one launch
         self.hist_fwd3 = int(os.environ.get("P2P_HIST_FWD3", "1"))      # three shared kernel rows per pixel, all components in one workgroup
         self.hist_points = int(os.environ.get("P2P_HIST_POINTS", "1"))  # real image: contraction over its distinct colours
         self.split_prep = int(os.environ.get("P2P_SPLIT_PREP", "1"))    # weight copies of the early-Adam part refreshed right behind it
@@ -743,8 +744,9 @@ class Pix2PixEngine:
                 P["early_ev"] = torch.cuda.Event()
                 P["early_ev"].record(torch.cuda.current_stream())
 
-    def generator_forward(self, P, masks=None):
-        """UnetGenerator forward up to the pre-activation head output z (networks.py:80-98)."""
+    def generator_forward(self, P, masks=None, head=True):
+        """UnetGenerator forward up to the pre-activation head output z (networks.py:80-98).  head=False stops in front of
+        the head convolution (the indexed train step fuses it with the softmax, p2p_head_softmax_cce)."""
         B, S = P["B"], self.S
         c = P["c"]
         P["rk_d"], P["rk_u"] = {}, {}
@@ -787,7 +789,8 @@ class Pix2PixEngine:
                            L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i])
             lo_view = c[i].view()
         # head: Conv2D(out, 4, stride 1, SAME, bias) (networks.py:75-78)
-        self._conv(P, L.OP_G, "G", "last", B, S, c[6].view(), P["z"].view(), stride=1, bias=self.G.p("last.bias"))
+        if head:
+            self._conv(P, L.OP_G, "G", "last", B, S, c[6].view(), P["z"].view(), stride=1, bias=self.G.p("last.bias"))
         P["early_masks"] = False
 
     def discriminator_forward(self, P, N2):
@@ -867,6 +870,7 @@ class Pix2PixEngine:
         L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), inv_bce,
                C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.loss_part), _stream())
         P["skip_g_through_d"] = False
+        P["head_dbias_done"] = False
         self.discriminator_backward(P, B)
         if lambda_hist is not None:
             self.side_hist.join()
@@ -880,7 +884,8 @@ class Pix2PixEngine:
         """Backward of UnetGenerator from dz (the gradient at the head's pre-activation)."""
         B, S = P["B"], self.S
         c, gc, ga = P["c"], P["gc"], P["ga"]
-        self._wgrad(P, "G", "last", B, S, c[6].view(), P["dz"].view(), stride=1, dbias=self.G.g("last.bias"))
+        dbias = None if P.get("head_dbias_done") else self.G.g("last.bias")      # the fused indexed head already summed it
+        self._wgrad(P, "G", "last", B, S, c[6].view(), P["dz"].view(), stride=1, dbias=dbias)
         # d(concat6): only the 32 channels of up6's output are needed (the source image has no gradient)
         self._conv(P, L.OP_P, "G", "last", B, S, P["dz"].view(), gc[6].view(), stride=1, ncols=UP_FILTERS[5])
         rk_gc = {6: (1, 1)}
@@ -1119,12 +1124,24 @@ class Pix2PixEngine:
         self._pack_source(P, src_t, with_disc=True)
         self._pack(P, real_t, P["dcat"].view(coff=0), 1)
         self._early_side(P, masks, apply_update)
-        self.generator_forward(P, masks)
+        fused = (self.use_mfma and self.use_head_fused and
+                 L.lib().p2p_head_softmax_ok(self.dtype, B, S, S, self.c6_ch, self.out_ch))
+        self.generator_forward(P, masks, head=not fused)
         real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
         inv_pix = 1.0 / (Bg * S * S)
-        L.call("p2p_softmax_cce_argmax", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
-               C.byref(fake_view), float(lambda_segmentation) * inv_pix, inv_pix, C.byref(P["dz"].view()), NULL,
-               _p(self._softmax_part()), _p(self.losses, 5), _stream())
+        P["head_dbias_done"] = fused
+        if fused:
+            # conv + bias + softmax + CCE + argmax + gradient (+ bias gradient) in one launch: the logits are never written
+            if "head_ws" not in P:
+                P["head_ws"] = torch.empty(L.lib().p2p_head_softmax_workspace_bytes(B, S) // 4 + 4, dtype=torch.float32, device=self.device)
+            L.call("p2p_head_softmax_cce", self.dtype, B, S, S, self.c6_ch, self.out_ch, C.byref(P["c"][6].view()),
+                   _p(self.W[("G", "last")].wt), self.G.p("last.bias"), C.byref(real_view), C.byref(fake_view),
+                   float(lambda_segmentation) * inv_pix, inv_pix, C.byref(P["dz"].view()), self.G.g("last.bias"),
+                   _p(P["head_ws"]), _p(self.losses, 5), _stream())
+        else:
+            L.call("p2p_softmax_cce_argmax", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
+                   C.byref(fake_view), float(lambda_segmentation) * inv_pix, inv_pix, C.byref(P["dz"].view()), NULL,
+                   _p(self._softmax_part()), _p(self.losses, 5), _stream())
         self.discriminator_forward(P, 2 * B)
         h2 = S // 2
         L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), 1.0 / (Bg * h2 * h2),

@@ -121,11 +121,27 @@ def call_work(name, args, dtype):
         # per image PAIR at S = 64); bytes: the RGBA image in, three 64 x 64 planes out
         _, n, h, w = _ints(args, 4)
         return {"flops": 3 * 2.0 * 64 * 64 * h * w * n, "mfma": "f32", "bytes": n * (h * w * 4 + 3 * 64 * 64) * 4.0}
+    if name == "p2p_rgbuv_hist_fwd3":
+        # the same contraction, all three components in one workgroup; with a colour-point list (args[5]) the contraction
+        # runs over the image's distinct colours: no longer matrix work, priced by its bytes
+        _, n, h, w = _ints(args, 4)
+        listed = getattr(args[5], "value", None) not in (None, 0)
+        by = n * (h * w * 4 + 3 * 64 * 64) * 4.0
+        if listed:
+            return {"flops": 0.0, "mfma": None, "bytes": by}
+        return {"flops": 3 * 2.0 * 64 * 64 * h * w * n, "mfma": "f32", "bytes": by}
+    if name == "p2p_rgbuv_points":
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * 4 * 4.0}
     if name == "p2p_rgbuv_hist_hellinger_bwd":
         # closed-form backward: A = GH . kv and Bm = GH^T . ku per colour component = twice the forward
         _, n, h, w = _ints(args, 4)
         return {"flops": 2 * 3 * 2.0 * 64 * 64 * h * w * n, "mfma": "f32",
                 "bytes": n * (h * w * 4 + 3 * 3 * 64 * 64 + 3 * h * w * 4) * 4.0}
+    if name == "p2p_head_softmax_cce":
+        _, n, h, w, cin, ncls = _ints(args, 6)
+        return {"flops": 2.0 * n * h * w * 16 * cin * ncls, "mfma": mf,
+                "bytes": n * h * w * (cin + ncls + 16.0) * esz + 16 * cin * ncls * esz}
     if name == "p2p_softmax_cce_argmax":
         _, n, h, w, c = _ints(args, 5)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2.0 * c * esz + 2 * 8 * esz)}

@@ -83,7 +83,9 @@ def test_shared_row_histogram_and_colour_points_match_the_oracle(S):
     assert U.rel_err(dense_t, ref_t) < 1e-4 and U.rel_err(dense_n, ref_n) < 1e-4
     listed_t, npts, pts = _fwd3(tgt, points=True)
     assert U.rel_err(listed_t, ref_t) < 1e-4
-    assert np.abs(listed_t - dense_t).max() <= 2e-5 * dense_t.max()            # same numbers up to f32 summation order (measured 5e-6)
+    # same numbers up to f32 summation order: adding 14 000 equal terms one by one (dense) drifts by up to 6e-5 of the peak at
+    # 128x128, count x term (listed) does not -- both sit within the 1e-4 of the oracle asserted above
+    assert np.abs(listed_t - dense_t).max() <= 1e-4 * dense_t.max()
     tiles = (S * S + 1023) // 1024
     for n in range(3):
         k = int(npts[n])
@@ -95,7 +97,7 @@ def test_shared_row_histogram_and_colour_points_match_the_oracle(S):
     listed_n, npts_n, _ = _fwd3(noisy, points=True, cap=64)
     if S >= 64:
         assert (npts_n == -1).all()
-    assert np.abs(listed_n - dense_n).max() <= 2e-5 * dense_n.max()
+    assert np.abs(listed_n - dense_n).max() <= 1e-4 * dense_n.max()
     # determinism: the list is a function of the image alone
     again = _fwd3(tgt, points=True)
     assert np.array_equal(again[1], npts) and np.array_equal(again[0], listed_t)
@@ -228,6 +230,56 @@ def test_argmax_is_bit_exact_with_engineered_ties():
     assert np.array_equal(want, want_np)
     assert np.array_equal(got.cpu().numpy(), want_np)
     assert got[5].item() == 0
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_fused_indexed_head_matches_conv_softmax_cce_argmax(n):
+    """p2p_head_softmax_cce (bf16, 64x64): Conv2D(256, 4, stride 1, SAME (1, 2), bias) + softmax + CCE + argmax + gradient + bias
+    gradient in one launch, against the f64 evaluation of the same bf16-rounded inputs (networks.py:75-78,
+    pix2pix_model.py:268,273-293,300-301)."""
+    import torch.nn.functional as F
+    dtype, S, cin, cpad, Cn = L.BF16, 64, 33, 40, 256
+    rng = np.random.default_rng(38 + n)
+    x = U.q(rng.normal(size=(n, S, S, cin)), dtype)
+    w = U.q(0.08 * rng.normal(size=(4, 4, cin, Cn)), dtype)            # HWIO
+    bias = (0.1 * rng.normal(size=Cn)).astype(np.float32)
+    tgt = rng.integers(0, Cn, size=(n, S, S, 1)).astype(np.int32)
+    assert L.lib().p2p_head_softmax_ok(dtype, n, S, S, cpad, Cn)
+    xb = E.HaloBuf(n, S, S, cpad, dtype, U.DEV)
+    xb.t[:, 2:-2, 2:-2, :cin] = U.dev(x, U.tdt(dtype))
+    wt = np.zeros((16, Cn, cpad), np.float32)                            # op-G copy wt[tap][d][g]
+    wt[:, :, :cin] = w.reshape(16, cin, Cn).transpose(0, 2, 1)
+    wt_d = U.dev(wt.reshape(-1), U.tdt(dtype))
+    tb = U.halo_from(np.concatenate([tgt.astype(np.float32), np.zeros((n, S, S, 7), np.float32)], -1), dtype)
+    fb = E.HaloBuf(n, S, S, 8, dtype, U.DEV)
+    dz = E.HaloBuf(n, S, S, Cn, dtype, U.DEV)
+    ws = torch.full((L.lib().p2p_head_softmax_workspace_bytes(n, S) // 4 + 4,), float("nan"), dtype=torch.float32, device=U.DEV)
+    loss = torch.zeros(2, dtype=torch.float32, device=U.DEV)
+    dbias = torch.full((Cn,), float("nan"), dtype=torch.float32, device=U.DEV)
+    inv, lam = 1.0 / (n * S * S), 0.5
+    L.call("p2p_head_softmax_cce", dtype, n, S, S, cpad, Cn, C.byref(xb.view()), U.ptr(wt_d), U.ptr(U.dev(bias)), C.byref(tb.view()),
+           C.byref(fb.view()), lam * inv, inv, C.byref(dz.view()), U.ptr(dbias), U.ptr(ws), U.ptr(loss), U.stream())
+    torch.cuda.synchronize()
+    xt = torch.tensor(x, dtype=F64).permute(0, 3, 1, 2)
+    z = F.conv2d(F.pad(xt, (1, 2, 1, 2)), torch.tensor(w, dtype=F64).permute(3, 2, 0, 1), torch.tensor(bias, dtype=F64))
+    z = z.permute(0, 2, 3, 1).detach().requires_grad_(True)
+    seg = rg.categorical_crossentropy_from_logits(z, torch.tensor(tgt))
+    (lam * seg).backward()
+    p_ref = torch.softmax(z, -1).detach().numpy()
+    assert abs(float(loss[0]) - float(seg)) < 2e-5 * float(seg), (float(loss[0]), float(seg))
+    onehot = np.eye(Cn)[tgt[..., 0]]
+    assert abs(float(loss[1]) - np.abs(onehot - p_ref).mean()) < 1e-5
+    got_dz = U.halo_to_np(dz).astype(np.float64)
+    assert U.rel_err(got_dz, z.grad.numpy()) < 6e-3                      # the gradient is stored in bf16
+    # bias gradient = column sums of the STORED (rounded) gradient
+    np.testing.assert_allclose(dbias.cpu().numpy(), got_dz.sum(axis=(0, 1, 2)), rtol=2e-5, atol=1e-7)
+    # argmax: identical to the f64 argmax wherever the top two probabilities are not within f32 rounding of each other
+    idx = U.halo_to_np(fb)[..., 0].astype(np.int64)
+    ref_idx = p_ref.argmax(-1)
+    top2 = np.sort(p_ref, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-6 * top2[..., 1]
+    assert (idx == ref_idx)[clear].all() and clear.mean() > 0.99
+    assert not U.halo_to_np(fb)[..., 1:].any()                            # only channel 0 of the index pixel is written
 
 
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
