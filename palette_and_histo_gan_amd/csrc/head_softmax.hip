@@ -21,19 +21,28 @@
 #include "p2p_common.hpp"
 
 #define HS_W 64
-#define HS_ROWS 4
 #define HS_CIN 40
 #define HS_NCLS 256
 #define HS_PIXB (HS_CIN * 2)                         // 80 bytes per input pixel
 #define HS_STRIP_COLS (HS_W + 3)
 #define HS_STRIP_ROWB (HS_STRIP_COLS * HS_PIXB)      // 5360
-#define HS_STRIP_ROWS (HS_ROWS + 3)
-#define HS_STRIP_BYTES (HS_STRIP_ROWS * HS_STRIP_ROWB)   // 37520
-#define HS_STAGE_STEPS 5
-#define HS_STAGE_BYTES (HS_STAGE_STEPS * 8 * 1024)   // 40 KB: 5 K steps x 8 channel tiles x 64 lanes x 16 B
-#define HS_NSTAGE 8                                  // 4 kernel rows x 2 halves
-#define HS_RING 3
+#define HS_KSTEPS_ROW 10                             // 4 taps x 40 channels = 160 values of K per kernel row = 10 steps of 16
 #define HS_PATCH_PIXB 528                            // 512-byte gradient pixel + 16 bytes: conflict-free ds_write_b64 / ds_read_b128
+
+// Two shapes of the same kernel (ROWS output rows per workgroup = ROWS x 2 waves; SS K steps per weight stage; RING stages):
+//   <4, 5, 3>  8 waves, 160 KB of LDS: one workgroup per CU, the weights stream once per 4 rows;
+//   <2, 2, 3>  4 waves, 76 KB: TWO workgroups per CU -- the long softmax epilogue (exponentials, argmax, gradient, transposition)
+//              of one overlaps the MFMA loop of the other; the weights stream once per 2 rows (from L2).
+template <int ROWS, int SS, int RING> struct HsCfg {
+    static constexpr int NW = 2 * ROWS, NTHR = NW * 64, NPIX = ROWS * HS_W;
+    static constexpr int STRIP_ROWS = ROWS + 3, STRIP_BYTES = STRIP_ROWS * HS_STRIP_ROWB;
+    static constexpr int STAGE_BYTES = SS * 8 * 1024, NSTAGE = 4 * HS_KSTEPS_ROW / SS, PER_WAVE = SS * 8 / NW;
+    static constexpr int SHM_MAIN = ((STRIP_BYTES + 255) & ~255) + RING * STAGE_BYTES;
+    static constexpr int XCH_FLOATS = 6 * 2 * NPIX + 256 + 2 * NPIX + 4 * 256;        // exchange arrays, bias, per-pixel loss terms, bias-gradient partials
+    static constexpr int SHM_EPI = NPIX * HS_PATCH_PIXB + XCH_FLOATS * 4;
+    static constexpr int SHM = SHM_EPI > SHM_MAIN ? SHM_EPI : SHM_MAIN;
+    static_assert(HS_KSTEPS_ROW % SS == 0 && (SS * 8) % NW == 0, "stage shape");
+};
 
 struct HsArgs {
     const char* in; long long in_img; int in_row;     // c6 view (element strides, ld = HS_CIN)
@@ -53,7 +62,11 @@ __device__ __forceinline__ void hs_glds16(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
+template <int ROWS, int SS, int RING>
+__global__ __launch_bounds__(ROWS * 128) void head_softmax_kernel(HsArgs a) {
+    typedef HsCfg<ROWS, SS, RING> K;
+    constexpr int NW = K::NW, NTHR = K::NTHR, NPIX = K::NPIX, HS_STRIP_ROWS = K::STRIP_ROWS, HS_STRIP_BYTES = K::STRIP_BYTES;
+    constexpr int HS_STAGE_BYTES = K::STAGE_BYTES, HS_NSTAGE = K::NSTAGE, HS_RING = RING, PER_WAVE = K::PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* strip = smem;
     char* ring = smem + ((HS_STRIP_BYTES + 255) & ~255);
@@ -61,14 +74,14 @@ __global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cw = wave & 1, pr = wave >> 1;            // channel half, output row of the tile
     const int h = lane >> 5, li = lane & 31;
-    const int tiles_per_img = a.H / HS_ROWS;
-    const int n = blockIdx.x / tiles_per_img, y0 = (blockIdx.x % tiles_per_img) * HS_ROWS;
+    const int tiles_per_img = a.H / ROWS;
+    const int n = blockIdx.x / tiles_per_img, y0 = (blockIdx.x % tiles_per_img) * ROWS;
 
     // ---- staging ---------------------------------------------------------------------------------------------------
     {   // input strip: rows y0-1 .. y0+5, columns -1 .. 65, each row 5360 contiguous bytes in HBM
         constexpr int CPR = HS_STRIP_ROWB / 16, TOTAL = HS_STRIP_ROWS * CPR;      // 335 chunks per row
         const char* base = a.in + ((long long)n * a.in_img + (long long)(y0 - 1) * a.in_row - 1) * HS_PIXB;
-        for (int c0 = wave * 64; c0 < TOTAL; c0 += 512) {
+        for (int c0 = wave * 64; c0 < TOTAL; c0 += NTHR) {
             const int ci = c0 + lane;
             if (ci < TOTAL) {
                 const int r = ci / CPR, cc = ci - r * CPR;
@@ -76,15 +89,17 @@ __global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
             }
         }
     }
-    // weight stage st = (kh, half): block (s, ct) = 1 KB in fragment order; wave w stages channel tile ct = w of every step
+    // weight stage st: SS consecutive K steps of one kernel row; block (s, ct) = 1 KB in fragment order, dealt round-robin to the waves
+    constexpr int SPR = HS_KSTEPS_ROW / SS;            // stages per kernel row
     auto stage_w = [&](int st, char* buf) {
-        const int kh = st >> 1, s0 = (st & 1) * HS_STAGE_STEPS;
+        const int kh = st / SPR, s0 = (st % SPR) * SS;
 #pragma unroll
-        for (int s = 0; s < HS_STAGE_STEPS; ++s) {
+        for (int q = 0; q < PER_WAVE; ++q) {
+            const int blk = q * NW + wave, s = blk >> 3, ct = blk & 7;
             const int kp = 16 * (s0 + s) + 8 * h;              // k' of this lane's 8 values inside the kernel row (0..159)
             const int kw = kp / HS_CIN, c = kp - kw * HS_CIN;
-            const char* src = a.wt + ((((long long)(kh * 4 + kw)) * HS_NCLS + wave * 32 + li) * HS_CIN + c) * 2;
-            hs_glds16(src, buf + (s * 8 + wave) * 1024);
+            const char* src = a.wt + ((((long long)(kh * 4 + kw)) * HS_NCLS + ct * 32 + li) * HS_CIN + c) * 2;
+            hs_glds16(src, buf + blk * 1024);
         }
     };
     stage_w(0, ring);
@@ -101,16 +116,16 @@ __global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
     // ---- main loop: 8 stages x 5 K steps x (4 channel tiles x 2 pixel tiles) ------------------------------------------
 #pragma unroll 1
     for (int st = 0; st < HS_NSTAGE; ++st) {
-        if (st + 1 < HS_NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HS_STAGE_STEPS) : "memory");
+        if (st + 1 < HS_NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (st + 2 < HS_NSTAGE) stage_w(st + 2, ring + ((st + 2) % HS_RING) * HS_STAGE_BYTES);
         const char* wbuf = ring + (st % HS_RING) * HS_STAGE_BYTES;
-        const int kh = st >> 1, s0 = (st & 1) * HS_STAGE_STEPS;
+        const int kh = st / SPR, s0 = (st % SPR) * SS;
         const char* brow = strip + (pr + kh) * HS_STRIP_ROWB + li * HS_PIXB + 16 * h;
 #pragma unroll
-        for (int s = 0; s < HS_STAGE_STEPS; ++s) {
+        for (int s = 0; s < SS; ++s) {
             bf16x8 bfr[2], afr[4];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(brow + j * 32 * HS_PIXB + 32 * (s0 + s));
@@ -127,15 +142,16 @@ __global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
     __syncthreads();          // every wave is done with the strip and the ring: both are re-used below
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------
-    // LDS: gradient patch [256 pixels][528 B] from offset 0; exchange arrays behind it
+    // LDS: gradient patch [NPIX pixels][528 B] from offset 0; exchange arrays behind it
     char* patch = smem;
-    float* xch = (float*)(smem + 256 * HS_PATCH_PIXB);        // [5][2 halves][256 pixels]
-    constexpr int XS = 2 * 256;
+    float* xch = (float*)(smem + NPIX * HS_PATCH_PIXB);
+    constexpr int XS = 2 * NPIX;                              // [2 channel halves][NPIX]
     float* xmax = xch, *xsum = xch + XS, *xzt = xch + 2 * XS, *xbest = xch + 3 * XS, *xpt = xch + 4 * XS;
     int* xbidx = (int*)(xch + 5 * XS);
     float* sbias = xch + 6 * XS;                               // [256]
-    float* spix = sbias + 256;                                 // [2][256]: per-pixel loss terms
-    if (tid < HS_NCLS) sbias[tid] = a.bias ? a.bias[tid] : 0.f;
+    float* spix = sbias + 256;                                 // [2][NPIX]: per-pixel loss terms
+    float* sdb = spix + 2 * NPIX;                              // [4][256]: bias-gradient partials of the pixel groups
+    for (int c = tid; c < HS_NCLS; c += NTHR) sbias[c] = a.bias ? a.bias[c] : 0.f;
     __syncthreads();
     const int chbase = cw * 128 + 4 * h;       // channel of (i, e): chbase + 32 i + (e & 3) + 8 (e >> 2)
     int tix[2];
@@ -152,53 +168,56 @@ __global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
                 m = fmaxf(m, acc[i][j][e]);
             }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        if (h == 0) xmax[cw * 256 + pr * 64 + x] = m;
+        if (h == 0) xmax[cw * NPIX + pr * 64 + x] = m;
     }
     __syncthreads();
-    float S[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int px = pr * 64 + j * 32 + li;
-        const float M = fmaxf(xmax[px], xmax[256 + px]);
+        const float M = fmaxf(xmax[px], xmax[NPIX + px]);
+        const int trel = tix[j] - chbase;              // the target's channel relative to this lane's first one
         float s = 0.f, zt = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float d = acc[i][j][e] - M;
-                if (chbase + 32 * i + (e & 3) + 8 * (e >> 2) == tix[j]) zt = d;      // z_t - max, before the exponential
-                const float ex = expf(d);
+                if (32 * i + (e & 3) + 8 * (e >> 2) == trel) zt = d;      // z_t - max, before the exponential
+                const float ex = __expf(d);            // v_exp_f32: the bf16 mode's exponentials (f32 mode keeps the generic path)
                 acc[i][j][e] = ex;
                 s += ex;
             }
         s += __shfl_xor(s, 32, 64);
         zt += __shfl_xor(zt, 32, 64);
-        if (h == 0) { xsum[cw * 256 + px] = s; xzt[cw * 256 + px] = zt; }
+        if (h == 0) { xsum[cw * NPIX + px] = s; xzt[cw * NPIX + px] = zt; }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int px = pr * 64 + j * 32 + li;
-        S[j] = xsum[px] + xsum[256 + px];
+        const float rS = 1.0f / (xsum[px] + xsum[NPIX + px]);
+        const int trel = tix[j] - chbase;
         float best = -1.f, pt = 0.f;
         int bidx = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int ch = chbase + 32 * i + (e & 3) + 8 * (e >> 2);
-                const float p = acc[i][j][e] / S[j];           // probabilities as tf.nn.softmax forms them: exp(z - max) / sum
-                if (p > best) { best = p; bidx = ch; }         // channels ascend with (i, e): strict '>' keeps the lowest index
-                if (ch == tix[j]) pt = p;
-                acc[i][j][e] = (p - (ch == tix[j] ? 1.f : 0.f)) * a.grad_scale;
+                const int cr = 32 * i + (e & 3) + 8 * (e >> 2);
+                const float p = acc[i][j][e] * rS;             // exp(z - max) / sum
+                if (p > best) { best = p; bidx = cr; }         // channels ascend with (i, e): strict '>' keeps the lowest index
+                const bool hit = cr == trel;
+                if (hit) pt = p;
+                acc[i][j][e] = (p - (hit ? 1.f : 0.f)) * a.grad_scale;
             }
+        bidx += chbase;
         {
             const float ob = __shfl_xor(best, 32, 64);
             const int oi = __shfl_xor(bidx, 32, 64);
             if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
             pt += __shfl_xor(pt, 32, 64);
         }
-        if (h == 0) { xbest[cw * 256 + px] = best; xbidx[cw * 256 + px] = bidx; xpt[cw * 256 + px] = pt; }
+        if (h == 0) { xbest[cw * NPIX + px] = best; xbidx[cw * NPIX + px] = bidx; xpt[cw * NPIX + px] = pt; }
         // gradient tile -> LDS patch [pixel][channel] in bf16, 4 consecutive channels per store
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -213,36 +232,50 @@ __global__ __launch_bounds__(512) void head_softmax_kernel(HsArgs a) {
     }
     __syncthreads();
     // argmax across the channel halves, loss terms, fake index: one thread per pixel
-    if (tid < 256) {
-        const int px = tid, r = px >> 6, x = px & 63, y = y0 + r;
-        float b0 = xbest[px], b1 = xbest[256 + px];
-        int i0 = xbidx[px], i1 = xbidx[256 + px];
+    for (int px = tid; px < NPIX; px += NTHR) {
+        const int r = px >> 6, x = px & 63, y = y0 + r;
+        float b0 = xbest[px], b1 = xbest[NPIX + px];
+        int i0 = xbidx[px], i1 = xbidx[NPIX + px];
         if (b1 > b0 || (b1 == b0 && i1 < i0)) { b0 = b1; i0 = i1; }
         a.fake[((long long)n * a.fk_img + (long long)y * a.fk_row + x) * a.fk_ld] = (bf16_t)(float)i0;
-        const float pt = xpt[px] + xpt[256 + px];
-        // per-pixel terms need S and z_t - max of THIS pixel: recomputed from the exchange arrays
-        spix[px] = logf(xsum[px] + xsum[256 + px]) - (xzt[px] + xzt[256 + px]);
-        spix[256 + px] = 2.f * (1.f - pt);           // sum_c |onehot_c - p_c| = (1 - p_t) + sum_{c != t} p_c
+        const float pt = xpt[px] + xpt[NPIX + px];
+        spix[px] = logf(xsum[px] + xsum[NPIX + px]) - (xzt[px] + xzt[NPIX + px]);      // -log softmax(z)[target]
+        spix[NPIX + px] = 2.f * (1.f - pt);           // sum_c |onehot_c - p_c| = (1 - p_t) + sum_{c != t} p_c
     }
     // whole 512-byte gradient pixels: 32 lanes x 16 B per pixel
     {
         const int sub = tid & 31;
-        for (int px = tid >> 5; px < 256; px += 16) {
+        for (int px = tid >> 5; px < NPIX; px += NTHR / 32) {
             const int r = px >> 6, x = px & 63, y = y0 + r;
             const f32x4 v = *(const f32x4*)(patch + px * HS_PATCH_PIXB + sub * 16);
             *(f32x4*)(a.dz + ((long long)n * a.dz_img + (long long)y * a.dz_row + x) * (HS_NCLS * 2) + sub * 16) = v;
         }
     }
-    // bias gradient partial: column sums of the ROUNDED gradient tile, pixels in order
-    if (a.dbias_part && tid < HS_NCLS) {
-        float s = 0.f;
-        for (int px = 0; px < 256; ++px) s += to_f32(*(const bf16_t*)(patch + px * HS_PATCH_PIXB + tid * 2));
-        a.dbias_part[(long long)blockIdx.x * HS_NCLS + tid] = s;
+    // bias gradient partial: column sums of the ROUNDED gradient tile; thread = (channel pair, pixel group), pixels in order
+    if (a.dbias_part) {
+        constexpr int NG = NTHR / 128;
+        const int cp = tid & 127, pg = tid >> 7;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+        for (int px = pg * (NPIX / NG); px < (pg + 1) * (NPIX / NG); ++px) {
+            const unsigned u = *(const unsigned*)(patch + px * HS_PATCH_PIXB + cp * 4);
+            s0 += __uint_as_float(u << 16);
+            s1 += __uint_as_float(u & 0xffff0000u);
+        }
+        sdb[pg * 256 + 2 * cp] = s0;
+        sdb[pg * 256 + 2 * cp + 1] = s1;
     }
     __syncthreads();
-    if (tid < 64) {           // fixed-order sums of the 256 per-pixel loss terms
+    if (a.dbias_part)
+        for (int c = tid; c < HS_NCLS; c += NTHR) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < NTHR / 128; ++g) s += sdb[g * 256 + c];
+            a.dbias_part[(long long)blockIdx.x * HS_NCLS + c] = s;
+        }
+    if (tid < 64) {           // fixed-order sums of the per-pixel loss terms
         float s0 = 0.f, s1 = 0.f;
-        for (int k = 0; k < 4; ++k) { s0 += spix[tid + 64 * k]; s1 += spix[256 + tid + 64 * k]; }
+        for (int k = 0; k < NPIX / 64; ++k) { s0 += spix[tid + 64 * k]; s1 += spix[NPIX + tid + 64 * k]; }
         s0 = wave_sum(s0);
         s1 = wave_sum(s1);
         if (tid == 0) {
@@ -273,13 +306,32 @@ __global__ __launch_bounds__(256) void head_bias_sum_kernel(const float* __restr
     if (threadIdx.x == 0) dbias[c] = s;
 }
 
+#include <stdlib.h>
+static int hs_rows() {       // output rows per workgroup: 2 (two workgroups per CU, default) or 4 (P2P_HEAD_ROWS=4)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("P2P_HEAD_ROWS"); v = (e && atoi(e) == 4) ? 4 : 2; }
+    return v;
+}
+
 extern "C" int p2p_head_softmax_ok(int dtype, int N, int H, int W, int cin_pad, int ncls) {
-    return dtype == P2P_BF16 && N > 0 && W == HS_W && H % HS_ROWS == 0 && cin_pad == HS_CIN && ncls == HS_NCLS;
+    return dtype == P2P_BF16 && N > 0 && W == HS_W && H % 4 == 0 && cin_pad == HS_CIN && ncls == HS_NCLS;
 }
 
 extern "C" long long p2p_head_softmax_workspace_bytes(int N, int H) {
-    const long long nwg = (long long)N * (H / HS_ROWS);
+    const long long nwg = (long long)N * (H / 2);        // the 2-row form has the most workgroups
     return nwg * (HS_NCLS + 2) * (long long)sizeof(float);
+}
+
+template <int ROWS, int SS, int RING>
+static void hs_launch(const HsArgs& a, int nwg, hipStream_t st) {
+    typedef HsCfg<ROWS, SS, RING> K;
+    static_assert(K::SHM <= 160 * 1024, "LDS budget");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)head_softmax_kernel<ROWS, SS, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SHM);
+        attr = true;
+    }
+    head_softmax_kernel<ROWS, SS, RING><<<dim3(nwg), dim3(K::NTHR), K::SHM, st>>>(a);
 }
 
 extern "C" int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad, int ncls, const p2p_tensor* in, const void* wt,
@@ -297,21 +349,14 @@ extern "C" int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad,
     a.target = (const bf16_t*)target->ptr; a.tg_img = target->img_stride; a.tg_row = target->row_stride; a.tg_ld = target->ld;
     a.fake = (bf16_t*)fake_idx->ptr; a.fk_img = fake_idx->img_stride; a.fk_row = fake_idx->row_stride; a.fk_ld = fake_idx->ld;
     a.dz = (char*)dz->ptr; a.dz_img = dz->img_stride; a.dz_row = dz->row_stride;
-    const int nwg = N * (H / HS_ROWS);
+    const int rows = hs_rows();
+    const int nwg = N * (H / rows);
     a.loss_part = workspace;
     a.dbias_part = dbias ? workspace + 2 * (long long)nwg : nullptr;
     a.grad_scale = grad_scale; a.inv_count = inv_count; a.H = H;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int SHM_EPI = 256 * HS_PATCH_PIXB + (6 * 512 + 256 + 512) * 4;                       // gradient patch + exchange arrays
-    constexpr int SHM_MAIN = ((HS_STRIP_BYTES + 255) & ~255) + HS_RING * HS_STAGE_BYTES;          // input strip + weight ring
-    constexpr int SHM = SHM_EPI > SHM_MAIN ? SHM_EPI : SHM_MAIN;
-    static_assert(SHM <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)head_softmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
-        attr = true;
-    }
-    head_softmax_kernel<<<dim3(nwg), dim3(512), SHM, st>>>(a);
+    if (rows == 4) hs_launch<4, 5, 3>(a, nwg, st);
+    else hs_launch<2, 2, 3>(a, nwg, st);
     int rc = p2p_check_launch("p2p_head_softmax_cce");
     if (rc) return rc;
     head_loss_sum_kernel<<<1, 256, 0, st>>>(a.loss_part, nwg, loss_out);
