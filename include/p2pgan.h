@@ -320,6 +320,13 @@ long long p2p_head_softmax_workspace_bytes(int N, int H);
 int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad, int ncls, const p2p_tensor* in, const void* wt,
                          const float* bias, const p2p_tensor* target, const p2p_tensor* fake_idx, float grad_scale,
                          float inv_count, const p2p_tensor* dz, float* dbias, float* workspace, float* loss_out, void* stream);
+/* Data gradient of that head through its first 32 input channels (the up6 slice of the concat; the source image has no
+ * gradient): op P, stride 1, out[n,y,x,g] = sum_{kh,kw,d} dz[n,y+1-kh,x+1-kw,d] * W[kh][kw][g][d], g < 32, with the op-P weight
+ * copy wn[16][w_rows][256] (bf16, IMG_SIZE 64: query p2p_head_dgrad_ok).  dz: haloed view of 256-channel pixels (zero halo of
+ * 2 pixels); out: view with >= 32 channels per pixel, channels [0, 32) are written. */
+int p2p_head_dgrad_ok(int dtype, int N, int H, int W, int ncls, int cout, int w_rows, int dz_ld, int out_ld);
+int p2p_head_dgrad(int dtype, int N, int H, int W, int ncls, int cout, const p2p_tensor* dz, const void* wn, int w_rows,
+                   const p2p_tensor* out, void* stream);
 
 /* ---- optimizer / parameter plumbing (pix2pix_model.py:28-29,81-83) ------------------------------- */
 

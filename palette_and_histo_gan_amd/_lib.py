@@ -72,6 +72,7 @@ SIGNATURES = {
     "p2p_rgbuv_hist_hellinger_bwd": [_i, _i, _i, _i, _TP, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
     "p2p_softmax_cce_argmax": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _f, _TP, _vp, _vp, _vp, _vp],
     "p2p_argmax_lastdim": [_vp, _ll, _i, _vp, _vp],
+    "p2p_head_dgrad": [_i, _i, _i, _i, _i, _i, _TP, _vp, _i, _TP, _vp],
     "p2p_head_softmax_cce": [_i, _i, _i, _i, _i, _i, _TP, _vp, _vp, _TP, _TP, _f, _f, _TP, _vp, _vp, _vp, _vp],
     "p2p_comm_unique_id": [_vp],
     "p2p_comm_init": [_vp, _i, _i, C.POINTER(_vp)],
@@ -96,6 +97,7 @@ SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int), "p2
            "p2p_wgemm_workspace_bytes": ([_i, _i, _i, _i, _i, _i], C.c_longlong),
            "p2p_rgbuv_hist_fwd3_workspace_bytes": ([_i], C.c_longlong),
            "p2p_head_softmax_ok": ([_i, _i, _i, _i, _i, _i], C.c_int),
+           "p2p_head_dgrad_ok": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_head_softmax_workspace_bytes": ([_i, _i], C.c_longlong),
            "p2p_view_colsum_workspace_bytes": ([_i, _i, _i, _i, _i, _TP], C.c_longlong),
            "p2p_weight_prep_task_blocks": ([_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_longlong)}

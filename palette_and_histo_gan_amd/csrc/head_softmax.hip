@@ -307,9 +307,9 @@ __global__ __launch_bounds__(256) void head_bias_sum_kernel(const float* __restr
 }
 
 #include <stdlib.h>
-static int hs_rows() {       // output rows per workgroup: 2 (two workgroups per CU, default) or 4 (P2P_HEAD_ROWS=4)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("P2P_HEAD_ROWS"); v = (e && atoi(e) == 4) ? 4 : 2; }
+static int hs_rows() {       // output rows per workgroup: 4 (default; measured 0.289 ms at B = 128) or 2 (P2P_HEAD_ROWS=2: 0.428 ms --
+    static int v = -1;       // the overlap of two workgroups per CU does not pay for streaming the weights twice as often)
+    if (v < 0) { const char* e = getenv("P2P_HEAD_ROWS"); v = (e && atoi(e) == 2) ? 2 : 4; }
     return v;
 }
 
@@ -362,4 +362,143 @@ extern "C" int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad,
     head_loss_sum_kernel<<<1, 256, 0, st>>>(a.loss_part, nwg, loss_out);
     if (dbias) head_bias_sum_kernel<<<dim3(HS_NCLS), 256, 0, st>>>(a.dbias_part, nwg, dbias);
     return p2p_check_launch("p2p_head_softmax_cce sums");
+}
+
+// =====================================================================================================================
+// Data gradient of the same head (pix2pix_model.py:78 through networks.py:75-78): op P, stride 1, 256 -> 32 channels
+//     g6[n,y,x,g] = sum_{kh,kw,d} dz[n, y+1-kh, x+1-kw, d] * W[kh][kw][g][d]          g < 32 (the source image has no gradient)
+// 137 GFLOP at B = 128 with K = 16 taps x 256 channels and only 32 output channels: every pixel fragment feeds ONE MFMA, so
+// the kernel lives on LDS bandwidth.  One workgroup (8 waves) owns 8 output rows x 64 pixels; wave w owns row w.  K is cut
+// into 8 chunks of 32 dz channels; per chunk the 11 x 67 pixel strip of 64-byte pixel slices (XOR-swizzled 16-byte slots:
+// conflict-free ds_read_b128 at 64-byte pixel pitch) and the chunk's weights of all 16 taps (32 KB, MFMA-fragment order)
+// are double-buffered in LDS; every wave issues the same number of LDS-DMA pieces per stage (counted s_waitcnt vmcnt).
+#define HD_ROWS 8
+#define HD_STRIP_ROWS (HD_ROWS + 3)
+#define HD_COLS (HS_W + 3)
+#define HD_STRIP_CHUNKS (HD_STRIP_ROWS * HD_COLS * 4)                 // 2948 16-byte slots
+#define HD_STRIP_ROUNDS ((HD_STRIP_CHUNKS + 511) / 512)               // 6 LDS-DMA rounds of 512 lanes
+#define HD_STRIP_BYTES (HD_STRIP_ROUNDS * 512 * 16)                   // 49152 (the tail is padding)
+#define HD_W_BYTES (32 * 1024)                                        // 16 taps x 2 K steps x 1 KB
+#define HD_STAGE (HD_STRIP_BYTES + HD_W_BYTES)
+#define HD_NCHUNK (HS_NCLS / 32)
+
+struct HdArgs {
+    const char* dz; long long dz_img; int dz_row;      // haloed view, 256-channel pixels
+    const char* wn;                                     // [16][w_rows][256] bf16
+    int w_rows;
+    char* out; long long out_img; int out_row; int out_ld;
+    int H;
+};
+
+__global__ __launch_bounds__(512) void head_dgrad_kernel(HdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    const int tiles_per_img = a.H / HD_ROWS;
+    const int n = blockIdx.x / tiles_per_img, y0 = (blockIdx.x % tiles_per_img) * HD_ROWS;
+    const char* dzbase = a.dz + ((long long)n * a.dz_img + (long long)(y0 - 2) * a.dz_row - 2) * (HS_NCLS * 2);
+
+    // per-lane source offsets of the strip slots this lane fills (the same for every channel chunk)
+    long long soff[HD_STRIP_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < HD_STRIP_ROUNDS; ++r) {
+        int sl = r * 512 + wave * 64 + lane;
+        if (sl >= HD_STRIP_CHUNKS) sl = HD_STRIP_CHUNKS - 1;            // padding slots re-fetch the last real one
+        const int pidx = sl >> 2, qs = sl & 3;
+        const int rr = pidx / HD_COLS, cidx = pidx - rr * HD_COLS;
+        const int q = qs ^ ((cidx >> 2) & 3);                            // swizzle: slot qs of a pixel holds source chunk q
+        soff[r] = ((long long)rr * a.dz_row + cidx) * (HS_NCLS * 2) + q * 16;
+    }
+    auto stage = [&](int dc, char* buf) {
+#pragma unroll
+        for (int r = 0; r < HD_STRIP_ROUNDS; ++r) hs_glds16(dzbase + soff[r] + dc * 64, buf + (r * 512 + wave * 64) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int blk = q * 8 + wave, tap = blk >> 1, s = blk & 1;
+            const char* src = a.wn + (((long long)tap * a.w_rows + li) * HS_NCLS + dc * 32 + s * 16 + 8 * h) * 2;
+            hs_glds16(src, buf + HD_STRIP_BYTES + blk * 1024);
+        }
+    };
+    constexpr int PER_WAVE = HD_STRIP_ROUNDS + 4;
+    stage(0, smem);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+#pragma unroll 1
+    for (int dc = 0; dc < HD_NCHUNK; ++dc) {
+        char* cur = smem + (dc & 1) * HD_STAGE;
+        // the other buffer was read during chunk dc-1: every wave is past that before anyone refills it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (dc + 1 < HD_NCHUNK) {
+            stage(dc + 1, smem + ((dc + 1) & 1) * HD_STAGE);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();             // chunk dc has landed for every wave
+        const char* wbuf = cur + HD_STRIP_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 16; ++tap) {
+            const int kh = tap >> 2, kw = tap & 3;
+            const int rr = wave + 3 - kh;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 afr = *(const bf16x8*)(wbuf + (tap * 2 + s) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cidx = j * 32 + li + 3 - kw;
+                    const int slot = ((rr * HD_COLS + cidx) << 2) | ((2 * s + h) ^ ((cidx >> 2) & 3));
+                    const bf16x8 bfr = *(const bf16x8*)(cur + slot * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[row = channel g][col = pixel]: g = (e & 3) + 8 (e >> 2) + 4 h; 4 consecutive channels per 8-byte store
+    const int y = y0 + wave;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = j * 32 + li;
+        char* op = a.out + ((long long)n * a.out_img + (long long)y * a.out_row + x) * a.out_ld * 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            typedef __attribute__((__vector_size__(4 * sizeof(bf16_t)))) bf16_t bf16x4;
+            bf16x4 v4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v4[k] = (bf16_t)acc[j][4 * g + k];
+            *(bf16x4*)(op + (8 * g + 4 * h) * 2) = v4;
+        }
+    }
+}
+
+extern "C" int p2p_head_dgrad_ok(int dtype, int N, int H, int W, int ncls, int cout, int w_rows, int dz_ld, int out_ld) {
+    return dtype == P2P_BF16 && N > 0 && W == HS_W && H % HD_ROWS == 0 && ncls == HS_NCLS && cout == 32 && w_rows >= 32 &&
+           dz_ld == HS_NCLS && out_ld >= 32 && out_ld % 4 == 0;
+}
+
+extern "C" int p2p_head_dgrad(int dtype, int N, int H, int W, int ncls, int cout, const p2p_tensor* dz, const void* wn, int w_rows,
+                              const p2p_tensor* out, void* stream) {
+    P2P_REQUIRE(dz && dz->ptr && wn && out && out->ptr, "p2p_head_dgrad: null pointer");
+    P2P_REQUIRE(p2p_head_dgrad_ok(dtype, N, H, W, ncls, cout, w_rows, dz->ld, out->ld), "p2p_head_dgrad: shape not supported (query p2p_head_dgrad_ok)");
+    P2P_REQUIRE(((uintptr_t)dz->ptr % 16) == 0 && ((uintptr_t)wn % 16) == 0 && ((uintptr_t)out->ptr % 8) == 0, "p2p_head_dgrad: alignment");
+    HdArgs a;
+    a.dz = (const char*)dz->ptr; a.dz_img = dz->img_stride; a.dz_row = dz->row_stride;
+    a.wn = (const char*)wn; a.w_rows = w_rows;
+    a.out = (char*)out->ptr; a.out_img = out->img_stride; a.out_row = out->row_stride; a.out_ld = out->ld;
+    a.H = H;
+    constexpr int SHM = 2 * HD_STAGE;
+    static_assert(SHM <= 160 * 1024, "LDS budget");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)head_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        attr = true;
+    }
+    head_dgrad_kernel<<<dim3(N * (H / HD_ROWS)), dim3(512), SHM, (hipStream_t)stream>>>(a);
+    return p2p_check_launch("p2p_head_dgrad");
 }

@@ -887,7 +887,14 @@ class Pix2PixEngine:
         dbias = None if P.get("head_dbias_done") else self.G.g("last.bias")      # the fused indexed head already summed it
         self._wgrad(P, "G", "last", B, S, c[6].view(), P["dz"].view(), stride=1, dbias=dbias)
         # d(concat6): only the 32 channels of up6's output are needed (the source image has no gradient)
-        self._conv(P, L.OP_P, "G", "last", B, S, P["dz"].view(), gc[6].view(), stride=1, ncols=UP_FILTERS[5])
+        lw = self.W[("G", "last")]
+        if (self.use_mfma and self.use_head_fused and lw.wn is not None and
+                L.lib().p2p_head_dgrad_ok(self.dtype, B, S, S, lw.cd, UP_FILTERS[5], up32(lw.cg), P["dz"].c, gc[6].c)):
+            # the indexed head's 256 -> 32 data gradient: strip-resident kernel of its own (K = 16 x 256, 32 outputs)
+            L.call("p2p_head_dgrad", self.dtype, B, S, S, lw.cd, UP_FILTERS[5], C.byref(P["dz"].view()), _p(lw.wn), up32(lw.cg),
+                   C.byref(gc[6].view()), _stream())
+        else:
+            self._conv(P, L.OP_P, "G", "last", B, S, P["dz"].view(), gc[6].view(), stride=1, ncols=UP_FILTERS[5])
         rk_gc = {6: (1, 1)}
         # up path, last to first
         for i in range(6, 0, -1):

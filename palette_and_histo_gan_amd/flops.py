@@ -142,6 +142,9 @@ def call_work(name, args, dtype):
         _, n, h, w, cin, ncls = _ints(args, 6)
         return {"flops": 2.0 * n * h * w * 16 * cin * ncls, "mfma": mf,
                 "bytes": n * h * w * (cin + ncls + 16.0) * esz + 16 * cin * ncls * esz}
+    if name == "p2p_head_dgrad":
+        _, n, h, w, ncls, cout = _ints(args, 6)
+        return {"flops": 2.0 * n * h * w * 16 * ncls * cout, "mfma": mf, "bytes": n * h * w * (ncls + cout) * esz + 16.0 * ncls * cout * esz}
     if name == "p2p_softmax_cce_argmax":
         _, n, h, w, c = _ints(args, 5)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2.0 * c * esz + 2 * 8 * esz)}

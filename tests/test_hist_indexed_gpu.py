@@ -282,6 +282,32 @@ def test_fused_indexed_head_matches_conv_softmax_cce_argmax(n):
     assert not U.halo_to_np(fb)[..., 1:].any()                            # only channel 0 of the index pixel is written
 
 
+def test_indexed_head_data_gradient_kernel():
+    """p2p_head_dgrad (bf16, 64x64): op P, stride 1, 256 -> first 32 of 33 input channels, against the f64 sum over taps"""
+    dtype, n, S, cg, cd = L.BF16, 2, 64, 33, 256
+    rng = np.random.default_rng(40)
+    dzv = U.q(rng.normal(size=(n, S, S, cd)), dtype)
+    w = U.q(0.05 * rng.normal(size=(16, cg, cd)), dtype)                  # [tap][g][d]
+    dzb = U.halo_from(dzv, dtype)
+    wn = torch.zeros(16 * E.up32(cg) * cd, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.zeros(16 * E.up32(cd) * E.pad8(cg), dtype=U.tdt(dtype), device=U.DEV)
+    L.call("p2p_weight_prep_pad", dtype, U.ptr(U.dev(w.reshape(-1))), cg, cd, U.ptr(wn), E.up32(cg), cd, U.ptr(wt), E.up32(cd),
+           E.pad8(cg), U.stream())
+    out = E.DenseBuf(n, S, S, 40, U.tdt(dtype), U.DEV)
+    out.t.fill_(7.0)
+    assert L.lib().p2p_head_dgrad_ok(dtype, n, S, S, cd, 32, E.up32(cg), cd, 40)
+    L.call("p2p_head_dgrad", dtype, n, S, S, cd, 32, C.byref(dzb.view()), U.ptr(wn), E.up32(cg), C.byref(out.view()), U.stream())
+    torch.cuda.synchronize()
+    dzp = np.pad(dzv.astype(np.float64), ((0, 0), (2, 2), (2, 2), (0, 0)))
+    ref = np.zeros((n, S, S, 32))
+    for kh in range(4):
+        for kw in range(4):
+            ref += dzp[:, 3 - kh:3 - kh + S, 3 - kw:3 - kw + S, :] @ w[kh * 4 + kw, :32, :].astype(np.float64).T
+    got = U.dense_to_np(out)
+    assert U.rel_err(got[..., :32], ref) < 6e-3                            # bf16 output
+    assert (got[..., 32:] == 7.0).all()                                    # the source / padding channels are not touched
+
+
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_softmax_cce_argmax_kernel(dtype):
     rng = np.random.default_rng(36)
