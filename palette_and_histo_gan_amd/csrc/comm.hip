@@ -4,7 +4,10 @@
 // streams; both paths all-reduce the same buffers: the flat generator / discriminator gradient buffers in buckets, the
 // loss scalars and, for the histogram model, the Hellinger sum of squares.
 // librccl.so is resolved at run time (dlopen) and only when p2p_comm_init is called: the library has no link-time
-// dependency on it, and a process that already carries an RCCL (PyTorch ships one) reuses that instance.
+// dependency on it.  A process that already carries an RCCL (PyTorch ships one) must not get a second runtime mapped beside
+// it: dlopen only re-uses a mapped library when the requested name equals its SONAME or path, so the already-loaded instance
+// is looked for first (RTLD_NOLOAD under every name it may carry); only when none is mapped is a fresh copy loaded, with
+// RTLD_LOCAL so that its symbols do not interpose on anything else in the process.
 #include "p2p_common.hpp"
 #include <dlfcn.h>
 #include <string.h>
@@ -27,9 +30,11 @@ Rccl g_rccl;
 
 bool rccl_load() {
     if (g_rccl.h) return true;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
-    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }       // the instance the process already has
+    if (!h)
+        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { p2p_set_error("p2p_comm: cannot load librccl.so (%s)", dlerror()); return false; }
     g_rccl.get_id = (get_id_fn)dlsym(h, "ncclGetUniqueId");
     g_rccl.init = (init_fn)dlsym(h, "ncclCommInitRank");
@@ -77,6 +82,7 @@ extern "C" int p2p_comm_init(const void* id_128_bytes, int rank, int world, void
 // In-place SUM all-reduce of n f32 values, ordered on `stream` like every other entry point of the library.
 extern "C" int p2p_comm_allreduce_sum(void* comm, float* buf, long long n, void* stream) {
     P2P_REQUIRE(comm && buf && n > 0, "p2p_comm_allreduce_sum: bad arguments");
+    P2P_REQUIRE(((uintptr_t)buf % 4) == 0, "p2p_comm_allreduce_sum: the buffer must be 4-byte aligned");
     if (!rccl_load()) return -1;
     int rc = g_rccl.allreduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm, (hipStream_t)stream);
     if (rc) return rccl_fail("p2p_comm_allreduce_sum", rc);
