@@ -175,7 +175,10 @@ def test_two_rank_fit_equals_one_rank_fit(tmp_path):
     assert sorted(os.listdir(ck_dir)) == [os.path.basename(ck_a[0])]
     # both ranks hold the same weights, and they are the 1-rank run's (f32 summation order, five Adam steps)
     assert np.array_equal(ga, gb) and np.array_equal(da, db)
-    assert np.abs(ga - g1).max() < 2e-4 and np.abs(da - d1).max() < 2e-4, (np.abs(ga - g1).max(), np.abs(da - d1).max())
+    # (Adam's first steps move every weight by ~lr whatever the gradient's size: an entry whose rounding-level gradient changes
+    # sign between the two summation orders moves by up to 2 lr = 4e-4 per step -- measured 4.3e-4 on a handful of entries)
+    assert np.abs(ga - g1).max() < 2e-3 and np.abs(da - d1).max() < 2e-3, (np.abs(ga - g1).max(), np.abs(da - d1).max())
+    assert np.abs(ga - g1).mean() < 2e-6, np.abs(ga - g1).mean()
 
 
 @pytest.mark.timeout(600)

@@ -11,6 +11,7 @@ not the yardstick here -- f32 mode is: the question this run answers is whether 
 trains to the same quality as the f32 parity mode.   python tools/quality_run.py [--steps 10080] > gpurun_out/quality_run.json
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -80,7 +81,8 @@ def main():
     for name in args.dtypes.split(","):
         train = D.SpriteRGBADataset(tr_s, tr_t, augment=False, batch_size=4, seed=47)
         test = D.SpriteRGBADataset(te_s, te_t, augment=False, batch_size=4, seed=48)
-        model = M.Pix2PixModel(train, test, "front2right", f"quality-{name}", lambda_l1=100.0, dtype=name, seed=47)
+        with contextlib.redirect_stdout(sys.stderr):
+            model = M.Pix2PixModel(train, test, "front2right", f"quality-{name}", lambda_l1=100.0, dtype=name, seed=47)
         curve = []
         orig = model.report_l1
 
@@ -90,7 +92,8 @@ def main():
             return tr, te
         model.report_l1 = spy
         t0 = time.time()
-        model.fit(args.steps, args.update_steps, callbacks=["evaluate_l1"])
+        with contextlib.redirect_stdout(sys.stderr):             # fit() prints its progress like the reference; stdout carries the JSON only
+            model.fit(args.steps, args.update_steps, callbacks=["evaluate_l1"])
         torch.cuda.synchronize()
         wall = time.time() - t0
         tr, te = orig(44)
