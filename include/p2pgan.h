@@ -362,6 +362,14 @@ typedef struct p2p_prep_task {
 long long p2p_weight_prep_task_blocks(int Cg, int Cd, int wn_rows, int wn_cols, int wt_rows, int wt_cols,
                                       int have_wn, int have_wt, int* tiles_g, int* tiles_d);
 int p2p_weight_prep_batched(int dtype, const p2p_prep_task* tasks_dev, int ntasks, long long total_blocks, void* stream);
+/* Keras Adam step (as p2p_adam_flat_dev, same expressions) on the masters of the listed layers AND their operand copies in one
+ * pass (tf.keras.optimizers.Adam.apply_gradients, pix2pix_model.py:81-83, followed by what p2p_weight_prep_batched derives):
+ * every task's master `w` lies inside `params`; grads / m / v are the flat buffers parallel to it.  Each kernel tensor must be
+ * listed ONCE; n_elems = sum of 16 * Cg * Cd over the tasks.  The small tensors (gamma, beta, bias) go through
+ * p2p_adam_flat_dev. */
+int p2p_adam_prep_batched(int dtype, long long n_elems, const p2p_prep_task* tasks_dev, int ntasks, long long total_blocks,
+                          float* params, const float* grads, float* m, float* v, const float* lr_t_dev, float beta1, float beta2,
+                          float eps, void* stream);
 
 
 /* dense f32 (or i32 if src_is_int) [N][H][W][C] host-layout batch -> view in `dtype` (dataset_utils.py:39-48 contract). */

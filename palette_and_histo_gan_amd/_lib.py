@@ -57,6 +57,7 @@ SIGNATURES = {
     "p2p_dropout_mask_dev": [_vp, _ll, _ll, _vp, _ll, _ll, _vp],
     "p2p_weight_prep": [_i, _vp, _i, _i, _vp, _vp, _vp],
     "p2p_weight_prep_batched": [_i, _vp, _i, _ll, _vp],
+    "p2p_adam_prep_batched": [_i, _ll, _vp, _i, _ll, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp],
     "p2p_pack_input": [_i, _i, _i, _i, _i, _vp, _i, _TP, _vp],
     "p2p_pack_pair": [_i, _i, _i, _i, _vp, _vp, _TP, _TP, _TP, _TP, _vp],
     "p2p_pack_input_multi": [_i, _i, _i, _i, _i, _vp, _i, _TP, _i, _vp],

@@ -12,6 +12,7 @@
 // followed by the chain rule through u, v = log-chroma and Iy.  Each component's pixel gradient goes to its own
 // f32 slab [3][N*HW][4]; the consumer (p2p_tanh_l1_bwd) sums the slabs on load.
 #include "p2p_common.hpp"
+#include <stdlib.h>
 
 #define HB 64                 // histogram size (histogram.py:36)
 #define HIST_EPS 1e-6f        // histogram.py:53
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256) void rgbuv_points_kernel(int H, int W, TView i
 #define H3_PS 3
 template <typename T>
 __global__ __launch_bounds__(256) void rgbuv_hist_fwd3_kernel(int H, int W, TView img, const f32x4* __restrict__ points,
-                                                             const int* __restrict__ npoints, int cap, float* __restrict__ part) {
+                                                             const int* __restrict__ npoints, int cap, float* __restrict__ part, int prio) {
+    if (prio) { if (blockIdx.y == 0) __builtin_amdgcn_s_setprio(3); else if (blockIdx.y == 1) __builtin_amdgcn_s_setprio(2); }      // see rgbuv_hist_bwd_kernel
     __shared__ float Aa[H3_PB][HB], Ab[H3_PB][HB];      // Iy*w*ka, Iy*w*kb   (row operands)
     __shared__ float Bb[H3_PB][HB], Bc[H3_PB][HB];      // kb, kc             (column operands)
     __shared__ float sa[H3_PB], sb[H3_PB], sc[H3_PB], siy[H3_PB];
@@ -337,7 +339,12 @@ __global__ __launch_bounds__(256) void hist_grad_prep_kernel(const float* __rest
 // ---- backward: d loss / d fake image, one f32 slab per component ------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView img, const float* __restrict__ gh,
-                                                            float* __restrict__ dimg, long long slab) {
+                                                            float* __restrict__ dimg, long long slab, int prio) {
+    // The three workgroups of an image (one per colour component) share a CU and run the same program: left alone they fall into
+    // lockstep -- all in their kernel-row (VALU) phase, then all in their MFMA phase, the matrix pipe idle half of the time.
+    // A different static priority per component lets the highest one run ahead; the phases then interleave (MI355X_MICROARCH.md,
+    // "Two waves per SIMD", items 4 and 9).
+    if (prio) { if (blockIdx.y == 0) __builtin_amdgcn_s_setprio(3); else if (blockIdx.y == 1) __builtin_amdgcn_s_setprio(2); }
     constexpr int PB = 64;
     __shared__ float G[HB][HB + 1];    // GH[i][j]; the odd row stride makes the transposed operand read (product 0) conflict-free
     __shared__ float KuT[HB][PB];      // ku[i][pixel]
@@ -477,8 +484,10 @@ extern "C" int p2p_rgbuv_hist_fwd3(int dtype, int N, int H, int W, const p2p_ten
     P2P_REQUIRE((points == nullptr) == (npoints == nullptr), "p2p_rgbuv_hist_fwd3: points and npoints come together");
     P2P_REQUIRE(((uintptr_t)workspace % 16) == 0 && ((uintptr_t)hist % 16) == 0, "p2p_rgbuv_hist_fwd3: alignment");
     hipStream_t st = (hipStream_t)stream;
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("P2P_HIST_PRIO"); prio = e ? atoi(e) : 1; }
     P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd3_kernel<T><<<dim3(N, H3_PS), 256, 0, st>>>(H, W, make_view(img), (const f32x4*)points,
-                                                                                        npoints, cap, workspace)));
+                                                                                        npoints, cap, workspace, prio)));
     int rc = p2p_check_launch("p2p_rgbuv_hist_fwd3");
     if (rc) return rc;
     rgbuv_hist_fold_kernel<<<dim3(N), 256, 0, st>>>(workspace, hist);
@@ -510,6 +519,8 @@ extern "C" int p2p_rgbuv_hist_hellinger_bwd(int dtype, int N, int H, int W, cons
     int rc = p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd prep");
     if (rc) return rc;
     long long slab = (long long)N * H * W * 4;
-    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd_kernel<T><<<dim3(N, 3), 256, 0, st>>>(H, W, make_view(fake), gh_ws, dimg, slab)));
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("P2P_HIST_PRIO"); prio = e ? atoi(e) : 1; }
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd_kernel<T><<<dim3(N, 3), 256, 0, st>>>(H, W, make_view(fake), gh_ws, dimg, slab, prio)));
     return p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd");
 }

@@ -182,6 +182,108 @@ __global__ void weight_prep_batched_kernel(const p2p_prep_task* __restrict__ tas
                         (float (*)[33])tile);
 }
 
+// ---- Adam + weight copies in one pass (SURVEY.md 2.3 K18 "also emits the bf16 weight copy") -------------------------------
+// The same tiling as the batched weight prep, but the master tile is UPDATED on the way: theta, g, m, v are read, the Keras
+// Adam step of adam_flat_dev_kernel is applied (same expressions: bit-identical results), theta, m, v are written back and the
+// fresh value goes straight into the two operand copies.  Saves the second read of the 117 MB master.  Every master element
+// lies in exactly one tile of its task; the caller lists every kernel ONCE.
+struct AdamCtx { float* p0; const float* g0; float* m0; float* v0; const float* lr_t; float b1, b2, eps; };
+
+#define ADAM_ONE(p, g, m, v)                                   \
+    do {                                                       \
+        m = c.b1 * (m) + (1.f - c.b1) * (g);                   \
+        v = c.b2 * (v) + (1.f - c.b2) * (g) * (g);             \
+        p = (p) - lr_t * (m) / (sqrtf(v) + c.eps);             \
+    } while (0)
+
+template <typename T>
+__global__ void adam_prep_batched_kernel(const p2p_prep_task* __restrict__ tasks, int ntasks, AdamCtx c) {
+    typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+    __shared__ float tile[64][65];
+    const long long b = blockIdx.x;
+    int ti = 0;
+    while (ti + 1 < ntasks && tasks[ti + 1].first_block <= b) ++ti;
+    const p2p_prep_task k = tasks[ti];
+    const int local = (int)(b - k.first_block);
+    const int per_tap = k.tiles_g * k.tiles_d;
+    const int t = local / per_tap, rem = local - t * per_tap;
+    const int gy = rem / k.tiles_d, dx = rem - gy * k.tiles_d;
+    const float lr_t = c.lr_t[0];
+    const long long base = (k.w - c.p0) + (long long)t * k.Cg * k.Cd;        // element index of this tap in the flat buffers
+    T* wn = (T*)k.wn;
+    T* wt = (T*)k.wt;
+    if (prep_tile64(k.Cg, k.Cd, k.wn_rows, k.wn_cols, k.wt_rows, k.wt_cols, wn != nullptr, wt != nullptr)) {
+        const int g0 = gy * 64, d0 = dx * 64;
+        const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 16 * i;
+            const long long e = base + (long long)(g0 + r) * k.Cd + d0 + c4;
+            f32x4 pv = *(const f32x4*)(c.p0 + e), mv = *(const f32x4*)(c.m0 + e), vv = *(const f32x4*)(c.v0 + e);
+            const f32x4 gv = *(const f32x4*)(c.g0 + e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ADAM_ONE(pv[q], gv[q], mv[q], vv[q]);
+            *(f32x4*)(c.p0 + e) = pv; *(f32x4*)(c.m0 + e) = mv; *(f32x4*)(c.v0 + e) = vv;
+            tile[r][c4] = pv[0]; tile[r][c4 + 1] = pv[1]; tile[r][c4 + 2] = pv[2]; tile[r][c4 + 3] = pv[3];
+            if (wn) {
+                vec4_t q4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) q4[q] = from_f32<T>(pv[q]);
+                *(vec4_t*)(wn + ((long long)t * k.Cg + g0 + r) * k.Cd + d0 + c4) = q4;
+            }
+        }
+        __syncthreads();
+        if (wt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = r0 + 16 * i;
+                vec4_t q4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) q4[q] = from_f32<T>(tile[c4 + q][d]);
+                *(vec4_t*)(wt + ((long long)t * k.Cd + d0 + d) * k.Cg + g0 + c4) = q4;
+            }
+        }
+        return;
+    }
+    float (*t32)[33] = (float (*)[33])tile;
+    const int g0 = gy * 32, d0 = dx * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int g = g0 + r, d = d0 + tx;
+        float val = 0.f;
+        if (g < k.Cg && d < k.Cd) {
+            const long long e = base + (long long)g * k.Cd + d;
+            float pv = c.p0[e], mv = c.m0[e], vv = c.v0[e];
+            const float gv = c.g0[e];
+            ADAM_ONE(pv, gv, mv, vv);
+            val = pv;
+            c.p0[e] = pv; c.m0[e] = mv; c.v0[e] = vv;
+        }
+        t32[r][tx] = val;
+        if (wn && g < k.wn_rows && d < k.wn_cols) wn[((long long)t * k.wn_rows + g) * k.wn_cols + d] = from_f32<T>(val);
+    }
+    __syncthreads();
+    if (wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int d = d0 + r, g = g0 + tx;
+            if (d < k.wt_rows && g < k.wt_cols) wt[((long long)t * k.wt_rows + d) * k.wt_cols + g] = from_f32<T>(t32[tx][r]);
+        }
+    }
+}
+
+extern "C" int p2p_adam_prep_batched(int dtype, long long n_elems, const p2p_prep_task* tasks_dev, int ntasks, long long total_blocks,
+                                     float* params, const float* grads, float* m, float* v, const float* lr_t_dev, float beta1,
+                                     float beta2, float eps, void* stream) {
+    P2P_REQUIRE(tasks_dev && ntasks >= 1 && ntasks <= 64 && total_blocks >= 1 && total_blocks < (1LL << 31) && n_elems > 0,
+                "p2p_adam_prep_batched: bad args");
+    P2P_REQUIRE(params && grads && m && v && lr_t_dev, "p2p_adam_prep_batched: null pointer");
+    P2P_REQUIRE(((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+                "p2p_adam_prep_batched: buffers must be 16-byte aligned");
+    AdamCtx c = {params, grads, m, v, lr_t_dev, beta1, beta2, eps};
+    P2P_DISPATCH_DTYPE(dtype, (adam_prep_batched_kernel<T><<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>(tasks_dev, ntasks, c)));
+    return p2p_check_launch("p2p_adam_prep_batched");
+}
+
 extern "C" long long p2p_weight_prep_task_blocks(int Cg, int Cd, int wn_rows, int wn_cols, int wt_rows, int wt_cols,
                                                  int have_wn, int have_wt, int* tiles_g, int* tiles_d) {
     int gmax = Cg, dmax = Cd;

@@ -74,57 +74,11 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
     // Strips are double-buffered when the plan left room (a.nbuf == 2): the LDS-DMA of strip s+1 is issued before strip s is
     // contracted and waited for after it, so staging (HBM latency + issue) hides behind the MFMAs instead of alternating with them.
     const int buf_bytes = a.buf_bytes;
-    // The strip geometry is the same for every strip of a launch: the (row, pixel, chunk) decomposition of every 16-byte slot
-    // a lane fills -- two integer divisions, the swizzle and a 64-bit product per slot -- is taken ONCE (8-wave form: the
-    // few-channel layers are streams of short strips whose staging was bound by exactly this address arithmetic); a strip then
-    // costs one 64-bit add per slot.  The 16-wave form has no registers to spare for the offset tables and keeps the direct form.
-    constexpr bool PRE = TPW == 2 && GT * DT <= 2;                 // (the 4-tile 8-wave forms have no registers to spare either)
-    constexpr int HR = PRE ? 19 : 1, LR = PRE ? 9 : 1;             // rounds of NTHR slots: 150 KB / 16 B / 512 lanes
-    const int LWp = a.pack == 2 ? TW + 3 : TW, LHp = a.pack == 2 ? TH + 3 : TH, lo_org = a.pack == 2 ? -2 : 0;
-    const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row, hcpp = hpB >> 4;
-    const int lchunks_row = (LWp * lpB) >> 4, lchunks = LHp * lchunks_row, lcpp = lpB >> 4;
-    int hoffs[HR], loffs[LR];
-    const bool pre_ok = PRE && hchunks <= HR * NTHR && lchunks <= LR * NTHR;
-    if (pre_ok) {
-#pragma unroll
-        for (int k = 0; k < HR; ++k) {
-            const int ci = k * NTHR + wave * 64 + lane;
-            hoffs[k] = -1;
-            if (ci < hchunks) {
-                int rr = ci / hchunks_row, cc = ci - rr * hchunks_row;
-                cc ^= ((cc >> 4) & mh) << 2;
-                int px = cc / hcpp, ch = cc - px * hcpp;
-                if (px >= RW) px = RW - 1;
-                hoffs[k] = (rr * a.hi_row + px) * hgB + ch * 16;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < LR; ++k) {
-            const int ci = k * NTHR + wave * 64 + lane;
-            loffs[k] = -1;
-            if (ci < lchunks) {
-                const int cs = ci ^ (((ci >> 4) & ml) << 2);
-                int rr = cs / lchunks_row, cc = cs - rr * lchunks_row;
-                int px = cc / lcpp, ch = cc - px * lcpp;
-                loffs[k] = (rr * a.lo_row + px) * lgB + ch * 16;
-            }
-        }
-    }
     auto stage_strip = [&](int strip, char* hiB, char* loB) {
         if (a.abl == 2) return;
         const int n = strip / a.strips_per_img, y0 = (strip % a.strips_per_img) * TH;
-        if (pre_ok) {
-            const char* hbase = a.hi + ((long long)n * a.hi_img + (long long)(S * y0 - 1) * a.hi_row - 1) * hgB + (hpB == hgB ? 0 : g0 * ESZ);
-            const char* lbase = a.lo + ((long long)n * a.lo_img + (long long)(y0 + lo_org) * a.lo_row + lo_org) * lgB + (lpB == lgB ? 0 : d0 * ESZ);
-#pragma unroll
-            for (int k = 0; k < HR; ++k)
-                if (k * NTHR < hchunks && hoffs[k] >= 0) glds16s(hbase + hoffs[k], hiB + (k * NTHR + wave * 64) * 16);
-#pragma unroll
-            for (int k = 0; k < LR; ++k)
-                if (k * NTHR < lchunks && loffs[k] >= 0) glds16s(lbase + loffs[k], loB + (k * NTHR + wave * 64) * 16);
-            return;
-        }
         // ---- the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
+        const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row, hcpp = hpB >> 4;
         for (int cI = wave * 64; cI < hchunks; cI += NTHR) {
             int ci = cI + lane;
             if (ci < hchunks) {
@@ -137,6 +91,8 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
                 glds16s(src, hiB + cI * 16);       // wave-uniform base + lane*16
             }
         }
+        const int LWp = a.pack == 2 ? TW + 3 : TW, LHp = a.pack == 2 ? TH + 3 : TH, lo_org = a.pack == 2 ? -2 : 0;
+        const int lchunks_row = (LWp * lpB) >> 4, lchunks = LHp * lchunks_row, lcpp = lpB >> 4;
         for (int cI = wave * 64; cI < lchunks; cI += NTHR) {
             int ci = cI + lane;
             if (ci < lchunks) {

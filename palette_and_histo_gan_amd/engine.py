@@ -274,6 +274,8 @@ class Pix2PixEngine:
         self._prep_table = {}
         self._head_prepped = False
         self.fuse_act_bwd = int(os.environ.get("P2P_FUSE_ACT_BWD", "1"))   # D.last data gradient + LeakyReLU backward in one launch
+        self.fuse_adam = os.environ.get("P2P_FUSE_ADAM", "1") != "0"          # Adam emits the operand copies of the weights it updates (one pass)
+        self._adam_tables = {}
         self.use_head_fused = os.environ.get("P2P_HEAD_FUSED", "1") != "0"    # indexed head: conv + softmax + CCE + argmax + gradient in one launch
         self.hist_fwd3 = int(os.environ.get("P2P_HIST_FWD3", "1"))      # three shared kernel rows per pixel, all components in one workgroup
         self.hist_points = int(os.environ.get("P2P_HIST_POINTS", "1"))  # real image: contraction over its distinct colours
@@ -359,6 +361,62 @@ class Pix2PixEngine:
         raw = torch.frombuffer(bytearray(bytes(tasks)), dtype=torch.uint8).to(self.device)
         self._prep_table[part] = (raw, len(specs), first)
         return self._prep_table[part]
+
+    def _adam_table(self, part):
+        """Device task table of p2p_adam_prep_batched for one part of the parameters -- "G_head": the generator kernels in front
+        of the last gradient bucket (what _adam_head updates early), "G_rest": the other generator kernels, "D": the
+        discriminator's kernels -- each kernel listed ONCE with its first copy set; "extra": the remaining copy sets (the
+        unpadded copies of the edge layers), refreshed by a plain p2p_weight_prep_batched afterwards.
+        Returns (table tensor, ntasks, total blocks, elements)."""
+        if part in self._adam_tables:
+            return self._adam_tables[part]
+        head_end = self.G.buckets[-1][0] if len(self.G.buckets) >= 2 else 0
+        specs, n_elems = [], 0
+        for (sid, name), lw in self.W.items():
+            store = self._store(sid)
+            in_head = sid == "G" and store.offsets[name + ".kernel"] + 16 * lw.cg * lw.cd <= head_end
+            where = "D" if sid == "D" else ("G_head" if in_head else "G_rest")
+            master = store.p(name + ".kernel")
+            sets = []
+            if lw.wt is not None or lw.wn is not None:
+                sets.append((master, lw.cg, lw.cd, lw.wn, up32(lw.cg), lw.lo_pad, lw.wt, up32(lw.cd), lw.hi_pad))
+            if lw.wd is not None:
+                sets.append((master, lw.cg, lw.cd, lw.wd, lw.cg, lw.cd, None, 0, 0))
+            if not sets:        # a kernel without copies still has to be updated: a task that writes none
+                sets.append((master, lw.cg, lw.cd, None, 0, 0, None, 0, 0))
+            if part == where:
+                specs.append(sets[0])
+                n_elems += 16 * lw.cg * lw.cd
+            elif part == "extra":
+                specs += sets[1:]
+        if not specs:
+            self._adam_tables[part] = (None, 0, 0, 0)
+            return self._adam_tables[part]
+        tasks = (L.PrepTask * len(specs))()
+        first = 0
+        for k, (master, cg, cd, wn, wn_r, wn_c, wt, wt_r, wt_c) in enumerate(specs):
+            tg, td = C.c_int(0), C.c_int(0)
+            nb = L.lib().p2p_weight_prep_task_blocks(cg, cd, wn_r, wn_c, wt_r, wt_c, int(wn is not None), int(wt is not None),
+                                                     C.byref(tg), C.byref(td))
+            t = tasks[k]
+            t.w = master.value
+            t.wn = wn.data_ptr() if wn is not None else None
+            t.wt = wt.data_ptr() if wt is not None else None
+            t.Cg, t.Cd, t.wn_rows, t.wn_cols, t.wt_rows, t.wt_cols = cg, cd, wn_r, wn_c, wt_r, wt_c
+            t.tiles_g, t.tiles_d, t.first_block = tg.value, td.value, first
+            first += nb
+        raw = torch.frombuffer(bytearray(bytes(tasks)), dtype=torch.uint8).to(self.device)
+        self._adam_tables[part] = (raw, len(specs), first, n_elems)
+        return self._adam_tables[part]
+
+    def _adam_prep(self, part):
+        """Keras Adam on the kernels of `part` and their operand copies in one launch (p2p_adam_prep_batched)."""
+        raw, ntasks, total, n_elems = self._adam_table(part)
+        if not ntasks:
+            return
+        store = self.D if part == "D" else self.G
+        L.call("p2p_adam_prep_batched", self.dtype, n_elems, _p(raw), ntasks, total, _p(store.params), _p(store.grads), _p(store.m),
+               _p(store.v), _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, _stream())
 
     def refresh_weight_copies(self, part="all"):
         """Re-derives the per-layer weight copies from the f32 masters; runs after every Adam step (one launch per part)."""
@@ -1007,6 +1065,10 @@ class Pix2PixEngine:
         else:
             return 0
         n = self.G.buckets[-1][0]
+        if self.fuse_adam:
+            self._adam_prep("G_head")          # update + operand copies in one pass over the 26 M head parameters
+            self._head_prepped = True
+            return n
         L.call("p2p_adam_flat_dev", _p(self.G.params), _p(self.G.grads), _p(self.G.m), _p(self.G.v), n,
                _p(self.G.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
         if self.split_prep:
@@ -1021,6 +1083,27 @@ class Pix2PixEngine:
         """Both optimizers step with gradients taken at the same pre-update weights (pix2pix_model.py:81-83).  `g_from`:
         first generator element not yet updated by _adam_head."""
         ticked, self._ticked = self._ticked, False      # counters already advanced by _early_side of this step
+        if self.fuse_adam:
+            for store in (self.G, self.D):
+                store.t += 1
+                if not ticked:
+                    L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
+            if g_from == 0:
+                self._adam_prep("G_head")
+            self._adam_prep("G_rest")
+            self._adam_prep("D")
+            for store in (self.G, self.D):       # gamma / beta / bias: the small-tensor tail of the flat buffers
+                lo_e, hi_e = store.small_range
+                if hi_e > lo_e:
+                    L.call("p2p_adam_flat_dev", _p(store.params, lo_e), _p(store.grads, lo_e), _p(store.m, lo_e), _p(store.v, lo_e),
+                           hi_e - lo_e, _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+            raw, ntasks, total, _ = self._adam_table("extra")
+            if ntasks:
+                L.call("p2p_weight_prep_batched", self.dtype, _p(raw), ntasks, total, _stream())
+            if not ticked:
+                L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
+            self._head_prepped = False
+            return
         for store in (self.G, self.D):
             store.t += 1
             if not ticked:

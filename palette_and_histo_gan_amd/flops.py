@@ -150,7 +150,7 @@ def call_work(name, args, dtype):
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2.0 * c * esz + 2 * 8 * esz)}
     if name == "p2p_adam_flat_dev":
         return {"flops": 0.0, "mfma": None, "bytes": 7 * 4.0 * int(args[4])}        # g, m, v, p in; m, v, p out
-    if name == "p2p_adam_prep":
+    if name == "p2p_adam_prep_batched":       # g, m, v, theta in; m, v, theta out; two operand copies out
         return {"flops": 0.0, "mfma": None, "bytes": (7 * 4.0 + 2 * esz) * int(args[1])}
     if name == "p2p_pack_pair":
         _, n, h, w = _ints(args, 4)

@@ -153,6 +153,42 @@ def test_two_adam_steps_match_oracle_f32():
         assert abs(np.linalg.norm(du_got) / np.linalg.norm(du_ref) - 1.0) < 1e-2, k
 
 
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_adam_fused_with_the_weight_copies_equals_the_two_launch_form(dtype):
+    """p2p_adam_prep_batched (Adam + operand copies in one pass) against p2p_adam_flat_dev followed by
+    p2p_weight_prep_batched: same masters, moments and copies after three steps (the expressions are the same; the compiler
+    may contract them differently in the two kernels, hence a last-bit tolerance on the masters)."""
+    B, S = 2, 64
+    rng, Gp, Dp, src, tgt, masks = setup_case(B, S, seed=77)
+    engines = []
+    for fused in (True, False):
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype)
+        eng.fuse_adam = fused
+        eng.set_params(to_np(Gp), to_np(Dp))
+        for _ in range(3):
+            eng.train_step_rgba(src, tgt, 100.0, masks=masks)
+        torch.cuda.synchronize()
+        engines.append(eng)
+    a, b = engines
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        assert sa.t == sb.t == 3
+        for buf in ("params", "m", "v"):
+            x, y = getattr(sa, buf), getattr(sb, buf)
+            assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()), buf
+    for key, lw in a.W.items():
+        for name in ("wt", "wn", "wd"):
+            ca, cb = getattr(lw, name), getattr(b.W[key], name)
+            assert (ca is None) == (cb is None)
+            if ca is not None:          # the copies follow their own masters: compare through f32 with the bf16 step as the unit
+                assert float((ca.float() - cb.float()).abs().max()) <= 2 ** -7 * float(cb.float().abs().max()) + 1e-12, (key, name)
+    # the copies ARE the rounded masters (layer with both orientations: up3)
+    lw = a.W[("G", "up3")]
+    w = a.G.view(a.G.params, "up3.kernel").reshape(16, lw.cg, lw.cd)
+    if lw.wn is not None:
+        assert torch.equal(lw.wn.view(16, lw.cg, lw.cd), w.to(lw.wn.dtype))
+    assert torch.equal(lw.wt.view(16, lw.cd, lw.cg), w.transpose(1, 2).to(lw.wt.dtype))
+
+
 def test_generate_is_forward_of_train_step():
     B, S = 2, 64
     rng, Gp, Dp, src, tgt, masks = setup_case(B, S, 23)
