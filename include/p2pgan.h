@@ -291,6 +291,11 @@ int p2p_hellinger_finish(const float* sq_sum, float inv_global_batch, float* los
 int p2p_rgbuv_hist_hellinger_bwd(int dtype, int N, int H, int W, const p2p_tensor* fake, const float* hist_true,
                                  const float* hist_pred, const float* tot_true, const float* tot_pred,
                                  const float* sq_sum, float coef, float* gh_ws, float* dimg, void* stream);
+/* The same gradient, the three colour components evaluated together from three shared kernel rows per pixel and summed in
+ * the kernel: ONE f32 slab [N*H*W][4] is written to `dimg` (consumer: p2p_tanh_l1_bwd with a one-slab gradient source). */
+int p2p_rgbuv_hist_hellinger_bwd3(int dtype, int N, int H, int W, const p2p_tensor* fake, const float* hist_true,
+                                  const float* hist_pred, const float* tot_true, const float* tot_pred, const float* sq_sum,
+                                  float coef, float* gh_ws, float* dimg, void* stream);
 
 /* ---- palette-index head (pix2pix_model.py:261-325) ------------------------------------------------------------ */
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     "p2p_hellinger_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "p2p_hellinger_finish": [_vp, _f, _vp, _vp],
     "p2p_rgbuv_hist_hellinger_bwd": [_i, _i, _i, _i, _TP, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
+    "p2p_rgbuv_hist_hellinger_bwd3": [_i, _i, _i, _i, _TP, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
     "p2p_softmax_cce_argmax": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _f, _TP, _vp, _vp, _vp, _vp],
     "p2p_argmax_lastdim": [_vp, _ll, _i, _vp, _vp],
     "p2p_head_dgrad": [_i, _i, _i, _i, _i, _i, _TP, _vp, _i, _TP, _vp],

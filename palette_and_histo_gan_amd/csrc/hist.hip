@@ -191,8 +191,7 @@ __global__ __launch_bounds__(256) void rgbuv_points_kernel(int H, int W, TView i
 #define H3_PS 3
 template <typename T>
 __global__ __launch_bounds__(256) void rgbuv_hist_fwd3_kernel(int H, int W, TView img, const f32x4* __restrict__ points,
-                                                             const int* __restrict__ npoints, int cap, float* __restrict__ part, int prio) {
-    if (prio) { if (blockIdx.y == 0) __builtin_amdgcn_s_setprio(3); else if (blockIdx.y == 1) __builtin_amdgcn_s_setprio(2); }      // see rgbuv_hist_bwd_kernel
+                                                             const int* __restrict__ npoints, int cap, float* __restrict__ part) {
     __shared__ float Aa[H3_PB][HB], Ab[H3_PB][HB];      // Iy*w*ka, Iy*w*kb   (row operands)
     __shared__ float Bb[H3_PB][HB], Bc[H3_PB][HB];      // kb, kc             (column operands)
     __shared__ float sa[H3_PB], sb[H3_PB], sc[H3_PB], siy[H3_PB];
@@ -339,12 +338,7 @@ __global__ __launch_bounds__(256) void hist_grad_prep_kernel(const float* __rest
 // ---- backward: d loss / d fake image, one f32 slab per component ------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView img, const float* __restrict__ gh,
-                                                            float* __restrict__ dimg, long long slab, int prio) {
-    // The three workgroups of an image (one per colour component) share a CU and run the same program: left alone they fall into
-    // lockstep -- all in their kernel-row (VALU) phase, then all in their MFMA phase, the matrix pipe idle half of the time.
-    // A different static priority per component lets the highest one run ahead; the phases then interleave (MI355X_MICROARCH.md,
-    // "Two waves per SIMD", items 4 and 9).
-    if (prio) { if (blockIdx.y == 0) __builtin_amdgcn_s_setprio(3); else if (blockIdx.y == 1) __builtin_amdgcn_s_setprio(2); }
+                                                            float* __restrict__ dimg, long long slab) {
     constexpr int PB = 64;
     __shared__ float G[HB][HB + 1];    // GH[i][j]; the odd row stride makes the transposed operand read (product 0) conflict-free
     __shared__ float KuT[HB][PB];      // ku[i][pixel]
@@ -442,6 +436,108 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
     }
 }
 
+// ---- backward, all three components of an image in one workgroup ---------------------------------------------------------
+// As in rgbuv_hist_fwd3_kernel the three kernel rows ka, kb, kc of the log-chroma differences a = lR - lG, b = lR - lB,
+// c = lG - lB (and their mirror images) serve every product of the closed form: component R has (u, v) = (a, b), G has (-a, c),
+// B has (-b, -c).  Six waves = (component, product): product 0 = GH kv (paired with ku: dIy and du), product 1 = GH^T ku (paired
+// with kv: dv).  Pixel batches of 32; per batch each kernel row is evaluated once (96 x 64 values instead of 3 x 2 x 32 x 64), the
+// pixel's logarithms once instead of three times, and the three components' pixel gradients are combined in the workgroup:
+// ONE f32 slab leaves instead of three.  grid = (image, pixel range).
+#define B3_PB 32
+template <typename T>
+__global__ __launch_bounds__(384) void rgbuv_hist_bwd3_kernel(int H, int W, TView img, const float* __restrict__ gh,
+                                                             float* __restrict__ dimg, int nsplit) {
+    __shared__ float G[3][HB][HB + 1];
+    __shared__ float K3[3][HB][B3_PB];           // ka, kb, kc as [bin][pixel]
+    __shared__ float sco[3][B3_PB], siy[B3_PB], sx[B3_PB][3];
+    __shared__ float r_diy[3][B3_PB], r_du[3][B3_PB], r_dv[3][B3_PB];
+    const int n = blockIdx.x, ps = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = H * W;
+    int chunk = (HW + nsplit - 1) / nsplit;
+    chunk = (chunk + B3_PB - 1) / B3_PB * B3_PB;
+    const int q0 = ps * chunk, q1 = min(HW, q0 + chunk);
+    for (int idx = tid; idx < 3 * HB * HB; idx += 384) {
+        const int c = idx >> 12, ij = idx & 4095;
+        G[c][ij >> 6][ij & 63] = gh[((long long)n * 3 + c) * HB * HB + ij];
+    }
+    const int c = wave >> 1, prod = wave & 1;
+    // (u, v) of component c in terms of the shared rows: array index, mirrored?, sign of the coordinate
+    const int ua = c == 2 ? 1 : 0, va = c == 0 ? 1 : 2;
+    const bool um = c != 0, vm = c == 2;
+    const int ra = prod == 0 ? va : ua, oa = prod == 0 ? ua : va;          // Rhs row set / the row set the result is paired with
+    const bool rm = prod == 0 ? vm : um, om = prod == 0 ? um : vm;
+    const float osign = om ? -1.f : 1.f;
+    const int pcol = lane & 31, hk = lane >> 5;
+    for (int p0 = q0; p0 < q1; p0 += B3_PB) {
+        __syncthreads();
+        if (tid < B3_PB) {
+            const int p = p0 + tid;
+            float a = 0.f, b = 0.f, cc = 0.f, iy = 1.f, x[3] = {1.f, 1.f, 1.f};
+            if (p < q1) {
+                load_rgb01<T>(img, n, p, W, x);
+                iy = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + HIST_EPS);
+                const float lr = logf(x[0] + HIST_EPS), lg = logf(x[1] + HIST_EPS), lb = logf(x[2] + HIST_EPS);
+                a = lr - lg; b = lr - lb; cc = lg - lb;
+            }
+            sco[0][tid] = a; sco[1][tid] = b; sco[2][tid] = cc; siy[tid] = iy;
+            sx[tid][0] = x[0]; sx[tid][1] = x[1]; sx[tid][2] = x[2];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 3 * HB * B3_PB; idx += 384) {
+            const int r = idx / (HB * B3_PB), rem = idx - r * (HB * B3_PB);
+            const int i = rem / B3_PB, p = rem - i * B3_PB;
+            K3[r][i][p] = iq_kernel(sco[r][p] - hist_center(i));
+        }
+        __syncthreads();
+        const float cval = osign * sco[oa][pcol];          // u or v of this component at the lane's pixel
+        float part0 = 0.f, part1 = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const int row = rt * 32 + (lane & 31);
+#pragma unroll 8
+            for (int kk = 0; kk < HB / 2; ++kk) {
+                const int k = 2 * kk + hk;
+                const float av = prod == 0 ? G[c][row][k] : G[c][k][row];
+                const float bv = K3[ra][rm ? 63 - k : k][pcol];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r2 = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+                const float kq = K3[oa][om ? 63 - r2 : r2][pcol];
+                const float t = cval - hist_center(r2);
+                part0 += acc[e] * kq;
+                part1 += acc[e] * (-2.0f * t * INV_SIGMA2) * kq * kq;
+            }
+        }
+        part0 += __shfl_xor(part0, 32, 64);
+        part1 += __shfl_xor(part1, 32, 64);
+        if (hk == 0) {
+            if (prod == 0) { r_diy[c][pcol] = part0; r_du[c][pcol] = siy[pcol] * part1; }
+            else { r_dv[c][pcol] = siy[pcol] * part1; }
+        }
+        __syncthreads();
+        if (tid < B3_PB && p0 + tid < q1) {
+            const float du0 = r_du[0][tid], dv0 = r_dv[0][tid], du1 = r_du[1][tid], dv1 = r_dv[1][tid], du2 = r_du[2][tid], dv2 = r_dv[2][tid];
+            // u0 = lR - lG, v0 = lR - lB;  u1 = lG - lR, v1 = lG - lB;  u2 = lB - lR, v2 = lB - lG    (histogram.py:72-74)
+            const float dl[3] = {(du0 + dv0) - du1 - du2, (du1 + dv1) - du0 - dv2, (du2 + dv2) - dv0 - dv1};
+            const float diy = (r_diy[0][tid] + r_diy[1][tid]) + r_diy[2][tid];
+            const float iy = siy[tid];
+            float* o = dimg + ((long long)n * HW + p0 + tid) * 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float xk = sx[tid][k];
+                o[k] = 0.5f * (dl[k] / (xk + HIST_EPS) + diy * xk / iy);          // x = img * 0.5 + 0.5
+            }
+            o[3] = 0.f;                                                           // alpha has no gradient
+        }
+    }
+}
+
 // hist_out[n][i][j][c] = raw[n][c][i][j] / sum(raw[n])  -- the reference's normalised (B,64,64,3) tensor (histogram.py:75-79)
 __global__ __launch_bounds__(256) void hist_normalize_kernel(const float* __restrict__ raw, float* __restrict__ out) {
     __shared__ float red[16];
@@ -484,10 +580,8 @@ extern "C" int p2p_rgbuv_hist_fwd3(int dtype, int N, int H, int W, const p2p_ten
     P2P_REQUIRE((points == nullptr) == (npoints == nullptr), "p2p_rgbuv_hist_fwd3: points and npoints come together");
     P2P_REQUIRE(((uintptr_t)workspace % 16) == 0 && ((uintptr_t)hist % 16) == 0, "p2p_rgbuv_hist_fwd3: alignment");
     hipStream_t st = (hipStream_t)stream;
-    static int prio = -1;
-    if (prio < 0) { const char* e = getenv("P2P_HIST_PRIO"); prio = e ? atoi(e) : 1; }
     P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd3_kernel<T><<<dim3(N, H3_PS), 256, 0, st>>>(H, W, make_view(img), (const f32x4*)points,
-                                                                                        npoints, cap, workspace, prio)));
+                                                                                        npoints, cap, workspace)));
     int rc = p2p_check_launch("p2p_rgbuv_hist_fwd3");
     if (rc) return rc;
     rgbuv_hist_fold_kernel<<<dim3(N), 256, 0, st>>>(workspace, hist);
@@ -509,6 +603,21 @@ extern "C" int p2p_hellinger_finish(const float* sq_sum, float inv_global_batch,
     return p2p_check_launch("p2p_hellinger_finish");
 }
 
+extern "C" int p2p_rgbuv_hist_hellinger_bwd3(int dtype, int N, int H, int W, const p2p_tensor* fake, const float* hist_true,
+                                             const float* hist_pred, const float* tot_true, const float* tot_pred,
+                                             const float* sq_sum, float coef, float* gh_ws, float* dimg, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && fake && fake->ptr && hist_true && hist_pred && tot_true && tot_pred && sq_sum && gh_ws && dimg,
+                "p2p_rgbuv_hist_hellinger_bwd3: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hist_grad_prep_kernel<<<dim3(N), 256, 0, st>>>(hist_true, hist_pred, tot_true, tot_pred, sq_sum, coef, gh_ws);
+    int rc = p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd3 prep");
+    if (rc) return rc;
+    int nsplit = 1;
+    while (N * nsplit < 512 && (H * W) / (nsplit * 2) >= 8 * B3_PB) nsplit *= 2;       // two workgroups per CU
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd3_kernel<T><<<dim3(N, nsplit), 384, 0, st>>>(H, W, make_view(fake), gh_ws, dimg, nsplit)));
+    return p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd3");
+}
+
 extern "C" int p2p_rgbuv_hist_hellinger_bwd(int dtype, int N, int H, int W, const p2p_tensor* fake, const float* hist_true,
                                             const float* hist_pred, const float* tot_true, const float* tot_pred,
                                             const float* sq_sum, float coef, float* gh_ws, float* dimg, void* stream) {
@@ -519,8 +628,6 @@ extern "C" int p2p_rgbuv_hist_hellinger_bwd(int dtype, int N, int H, int W, cons
     int rc = p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd prep");
     if (rc) return rc;
     long long slab = (long long)N * H * W * 4;
-    static int prio = -1;
-    if (prio < 0) { const char* e = getenv("P2P_HIST_PRIO"); prio = e ? atoi(e) : 1; }
-    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd_kernel<T><<<dim3(N, 3), 256, 0, st>>>(H, W, make_view(fake), gh_ws, dimg, slab, prio)));
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd_kernel<T><<<dim3(N, 3), 256, 0, st>>>(H, W, make_view(fake), gh_ws, dimg, slab)));
     return p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd");
 }

@@ -274,10 +274,13 @@ class Pix2PixEngine:
         self._prep_table = {}
         self._head_prepped = False
         self.fuse_act_bwd = int(os.environ.get("P2P_FUSE_ACT_BWD", "1"))   # D.last data gradient + LeakyReLU backward in one launch
-        self.fuse_adam = os.environ.get("P2P_FUSE_ADAM", "1") != "0"          # Adam emits the operand copies of the weights it updates (one pass)
+        # Adam emitting the operand copies of the weights it updates (one pass, p2p_adam_prep_batched): measured 0.198 ms against
+        # 0.187 ms for the flat Adam + batched copy launch on c2 (the tiled kernel streams slower than the flat one): off
+        self.fuse_adam = os.environ.get("P2P_FUSE_ADAM", "0") != "0"
         self._adam_tables = {}
         self.use_head_fused = os.environ.get("P2P_HEAD_FUSED", "1") != "0"    # indexed head: conv + softmax + CCE + argmax + gradient in one launch
         self.hist_fwd3 = int(os.environ.get("P2P_HIST_FWD3", "1"))      # three shared kernel rows per pixel, all components in one workgroup
+        self.hist_bwd3 = int(os.environ.get("P2P_HIST_BWD3", "1"))      # backward: the three components in one workgroup, one gradient slab
         self.hist_points = int(os.environ.get("P2P_HIST_POINTS", "1"))  # real image: contraction over its distinct colours
         self.split_prep = int(os.environ.get("P2P_SPLIT_PREP", "1"))    # weight copies of the early-Adam part refreshed right behind it
         self.refresh_weight_copies()
@@ -1137,9 +1140,11 @@ class Pix2PixEngine:
         # of the loss scalars (like the element-mean losses) yields the global value
         L.call("p2p_hellinger_finish", _p(P["h_sq"]), (1.0 / Bg) * (B / Bg), _p(self.losses, 4), _stream())
         coef = float(lambda_hist) / (2.0 * math.sqrt(2.0) * Bg)
-        L.call("p2p_rgbuv_hist_hellinger_bwd", L.F32, B, S, S, C.byref(fake_view), _p(P["h_real"]), _p(P["h_fake"]),
-               _p(P["h_tot"][0]), _p(P["h_tot"][1]), _p(P["h_sq"]), coef, _p(P["h_gh"]), _p(P["h_dimg"]), _stream())
-        return L.GSrc(P["h_dimg"].data_ptr(), 2, 3, B * S * S * 4, 4, 0)
+        bwd3 = self.hist_fwd3 and self.hist_bwd3
+        L.call("p2p_rgbuv_hist_hellinger_bwd3" if bwd3 else "p2p_rgbuv_hist_hellinger_bwd", L.F32, B, S, S, C.byref(fake_view),
+               _p(P["h_real"]), _p(P["h_fake"]), _p(P["h_tot"][0]), _p(P["h_tot"][1]), _p(P["h_sq"]), coef, _p(P["h_gh"]),
+               _p(P["h_dimg"]), _stream())
+        return L.GSrc(P["h_dimg"].data_ptr(), 2, 1 if bwd3 else 3, B * S * S * 4, 4, 0)
 
     def _hist_buffers(self, P, B):
         if "h_real" in P:

@@ -133,6 +133,9 @@ def call_work(name, args, dtype):
     if name == "p2p_rgbuv_points":
         _, n, h, w = _ints(args, 4)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * 4 * 4.0}
+    if name == "p2p_rgbuv_hist_hellinger_bwd3":
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 2 * 3 * 2.0 * 64 * 64 * h * w * n, "mfma": "f32", "bytes": n * (h * w * 4 + 3 * 3 * 64 * 64 + h * w * 4) * 4.0}
     if name == "p2p_rgbuv_hist_hellinger_bwd":
         # closed-form backward: A = GH . kv and Bm = GH^T . ku per colour component = twice the forward
         _, n, h, w = _ints(args, 4)

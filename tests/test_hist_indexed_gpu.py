@@ -139,6 +139,15 @@ def test_hellinger_loss_and_gradient_match_closed_form(size):
     # the gradient spans ~6 decades (1/(x+1e-6) on near-black pixels): compare in the max-norm and in L2
     assert U.rel_err(got, ref) < 2e-3
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-3
+    # the shared-row form (three components in one workgroup, ONE slab): same gradient
+    one = torch.full((B * size * size * 4,), float("nan"), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_rgbuv_hist_hellinger_bwd3", L.F32, B, size, size, C.byref(fb.view()), U.ptr(h_r), U.ptr(h_f), U.ptr(tot[0]),
+           U.ptr(tot[1]), U.ptr(sq), 1.0 / (2.0 * math.sqrt(2.0) * B), U.ptr(gh), U.ptr(one), U.stream())
+    got3 = one.view(B, size, size, 4).cpu().numpy()
+    assert np.count_nonzero(got3[..., 3]) == 0 and np.isfinite(got3).all()
+    assert U.rel_err(got3, ref) < 2e-3
+    assert np.linalg.norm(got3 - ref) / np.linalg.norm(ref) < 2e-3
+    assert np.linalg.norm(got3 - got) / np.linalg.norm(got) < 2e-5          # against the per-component form: f32 summation order only
 
 
 def test_histogram_model_train_step_matches_oracle():
