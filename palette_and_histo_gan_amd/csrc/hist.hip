@@ -389,28 +389,34 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
         float part0 = 0.f, part1 = 0.f;                    // sum_rows D*k  and  sum_rows D*g*k^2
         const int pcol = pt * 32 + (lane & 31);
         const float cval = coord[pcol];
+        // both 32-row tiles at once: two independent accumulation chains per wave (one chain of v_mfma_f32_32x32x2_f32 leaves
+        // the matrix pipe idle between dependent issues: r03 PMC 48 % busy, 50 % of the wave cycles issue-stalled), one read of
+        // the right-hand operand for both
+        f32x16 acc[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            f32x16 acc;
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
 #pragma unroll 8
-            for (int kk = 0; kk < HB / 2; ++kk) {
-                int k = 2 * kk + (lane >> 5);
-                const int row = rt * 32 + (lane & 31);
-                float a = prod == 0 ? G[row][k] : G[k][row];
-                float b = Rhs[k][pcol];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
+        for (int kk = 0; kk < HB / 2; ++kk) {
+            const int k = 2 * kk + (lane >> 5);
+            const int r0 = lane & 31, r1 = 32 + (lane & 31);
+            const float a0 = prod == 0 ? G[r0][k] : G[k][r0];
+            const float a1 = prod == 0 ? G[r1][k] : G[k][r1];
+            const float b = Rhs[k][pcol];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 float kq = Kown[row][pcol];
                 float t = cval - hist_center(row);
-                part0 += acc[e] * kq;
-                part1 += acc[e] * (-2.0f * t * INV_SIGMA2) * kq * kq;
+                part0 += acc[rt][e] * kq;
+                part1 += acc[rt][e] * (-2.0f * t * INV_SIGMA2) * kq * kq;
             }
-        }
         part0 += __shfl_xor(part0, 32, 64);
         part1 += __shfl_xor(part1, 32, 64);
         if ((lane >> 5) == 0) {
@@ -492,28 +498,31 @@ __global__ __launch_bounds__(384) void rgbuv_hist_bwd3_kernel(int H, int W, TVie
         __syncthreads();
         const float cval = osign * sco[oa][pcol];          // u or v of this component at the lane's pixel
         float part0 = 0.f, part1 = 0.f;
+        f32x16 acc[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            f32x16 acc;
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            const int row = rt * 32 + (lane & 31);
+            for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
 #pragma unroll 8
-            for (int kk = 0; kk < HB / 2; ++kk) {
-                const int k = 2 * kk + hk;
-                const float av = prod == 0 ? G[c][row][k] : G[c][k][row];
-                const float bv = K3[ra][rm ? 63 - k : k][pcol];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
+        for (int kk = 0; kk < HB / 2; ++kk) {
+            const int k = 2 * kk + hk;
+            const int r0 = lane & 31, r1 = 32 + (lane & 31);
+            const float a0 = prod == 0 ? G[c][r0][k] : G[c][k][r0];
+            const float a1 = prod == 0 ? G[c][r1][k] : G[c][k][r1];
+            const float bv = K3[ra][rm ? 63 - k : k][pcol];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r2 = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
                 const float kq = K3[oa][om ? 63 - r2 : r2][pcol];
                 const float t = cval - hist_center(r2);
-                part0 += acc[e] * kq;
-                part1 += acc[e] * (-2.0f * t * INV_SIGMA2) * kq * kq;
+                part0 += acc[rt][e] * kq;
+                part1 += acc[rt][e] * (-2.0f * t * INV_SIGMA2) * kq * kq;
             }
-        }
         part0 += __shfl_xor(part0, 32, 64);
         part1 += __shfl_xor(part1, 32, 64);
         if (hk == 0) {

@@ -15,7 +15,8 @@ from collections import defaultdict
 FAMILIES = ["brig_kernel", "igemm_kernel", "wgemm_kernel", "wgrad_small_kernel", "conv_strip_kernel", "conv_fewin_kernel", "conv_fewout_kernel",
             "norm_act_fwd_vec", "norm_act_bwd_vec", "norm_act_fwd_small", "norm_act_bwd_small", "adam_flat_dev_kernel",
             "weight_prep_batched_kernel", "act_bwd_vec_kernel", "pack_pair_kernel", "ws_slab_sum_kernel", "rgbuv_hist_fwd_kernel",
-            "rgbuv_hist_bwd_kernel", "softmax256_kernel"]
+            "rgbuv_hist_bwd_kernel", "softmax256_kernel", "rgbuv_hist_fwd3_kernel", "rgbuv_hist_bwd3_kernel",
+            "rgbuv_points_kernel", "head_softmax_kernel", "head_dgrad_kernel", "adam_prep_batched_kernel"]
 
 
 def main():

@@ -15,7 +15,10 @@ from collections import defaultdict
 FAMILIES = {"igemm_kernel": "p2p_igemm", "brig_kernel": "p2p_igemm", "wgemm_kernel": "p2p_wgemm", "norm_act_fwd_vec": "p2p_norm_act_fwd",
             "norm_act_bwd_vec": "p2p_norm_act_bwd", "adam_flat_dev_kernel": "p2p_adam_flat_dev",
             "weight_prep_kernel": "p2p_weight_prep_pad", "rgbuv_hist_fwd_kernel": "p2p_rgbuv_hist_fwd",
-            "rgbuv_hist_bwd_kernel": "p2p_rgbuv_hist_hellinger_bwd"}
+            "rgbuv_hist_bwd_kernel": "p2p_rgbuv_hist_hellinger_bwd", "rgbuv_hist_fwd3_kernel": "p2p_rgbuv_hist_fwd3",
+            "rgbuv_hist_bwd3_kernel": "p2p_rgbuv_hist_hellinger_bwd3", "head_softmax_kernel": "p2p_head_softmax_cce",
+            "head_dgrad_kernel": "p2p_head_dgrad", "wgrad_small_kernel": "p2p_wgrad_small", "conv_strip_kernel": "p2p_conv_strip",
+            "conv_fewin_kernel": "p2p_conv_fewin", "conv_fewout_kernel": "p2p_conv_fewout"}
 
 
 def load(folder, counter):
