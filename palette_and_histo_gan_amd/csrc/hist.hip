@@ -443,38 +443,51 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
 }
 
 // ---- backward, all three components of an image in one workgroup ---------------------------------------------------------
-// As in rgbuv_hist_fwd3_kernel the three kernel rows ka, kb, kc of the log-chroma differences a = lR - lG, b = lR - lB,
-// c = lG - lB (and their mirror images) serve every product of the closed form: component R has (u, v) = (a, b), G has (-a, c),
-// B has (-b, -c).  Six waves = (component, product): product 0 = GH kv (paired with ku: dIy and du), product 1 = GH^T ku (paired
-// with kv: dv).  Pixel batches of 32; per batch each kernel row is evaluated once (96 x 64 values instead of 3 x 2 x 32 x 64), the
-// pixel's logarithms once instead of three times, and the three components' pixel gradients are combined in the workgroup:
-// ONE f32 slab leaves instead of three.  grid = (image, pixel range).
-#define B3_PB 32
+// Measured model of these kernels (r03 PMC + timing): v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and does not overlap
+// with the other waves' vector instructions on its SIMD -- kernel time = (matrix cycles + vector cycles) per SIMD.  The lever is
+// the vector instruction count per pixel, on evenly loaded SIMDs.  As in rgbuv_hist_fwd3_kernel the three kernel rows ka, kb, kc
+// of the log-chroma differences a = lR - lG, b = lR - lB, c = lG - lB (and their mirror images) serve every product of the
+// closed form: component R has (u, v) = (a, b), G has (-a, c), B has (-b, -c).  Twelve waves = (component, product, row tile):
+// product 0 = GH kv (paired with ku: dIy and du), product 1 = GH^T ku (paired with kv: dv); three waves per SIMD.  Per batch
+// of 64 pixels every kernel row is evaluated once (3 x 64 x 64 values instead of 3 x 2 x 64 x 64), the pixel's logarithms once
+// instead of three times, the epilogue keeps two running sums per pixel (sum D k, sum D k^2 (coord - d)) with the bin
+// centres in registers, and the three components' pixel gradients are combined here: ONE f32 slab leaves.
+#define B3_PB 64
+#define B3_NT 768
 template <typename T>
-__global__ __launch_bounds__(384) void rgbuv_hist_bwd3_kernel(int H, int W, TView img, const float* __restrict__ gh,
-                                                             float* __restrict__ dimg, int nsplit) {
-    __shared__ float G[3][HB][HB + 1];
-    __shared__ float K3[3][HB][B3_PB];           // ka, kb, kc as [bin][pixel]
-    __shared__ float sco[3][B3_PB], siy[B3_PB], sx[B3_PB][3];
-    __shared__ float r_diy[3][B3_PB], r_du[3][B3_PB], r_dv[3][B3_PB];
+__global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TView img, const float* __restrict__ gh,
+                                                               float* __restrict__ dimg, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) char b3_smem[];
+    float (*G)[HB][HB + 1] = (float (*)[HB][HB + 1])b3_smem;                         // [3][64][65]
+    float (*K3)[HB][B3_PB] = (float (*)[HB][B3_PB])(b3_smem + 3 * HB * (HB + 1) * 4); // ka, kb, kc as [bin][pixel]
+    float* fl = (float*)(b3_smem + 3 * HB * (HB + 1) * 4 + 3 * HB * B3_PB * 4);
+    float (*sco)[B3_PB] = (float (*)[B3_PB])fl;               // [3] a, b, c
+    float* siy = fl + 3 * B3_PB;
+    float (*sx)[4] = (float (*)[4])(siy + B3_PB);             // [PB][4]
+    float (*racc)[2][3][B3_PB] = (float (*)[2][3][B3_PB])(siy + B3_PB + 4 * B3_PB);   // [3 comps][2 row tiles][diy | du | dv][pixel]
     const int n = blockIdx.x, ps = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = H * W;
     int chunk = (HW + nsplit - 1) / nsplit;
     chunk = (chunk + B3_PB - 1) / B3_PB * B3_PB;
     const int q0 = ps * chunk, q1 = min(HW, q0 + chunk);
-    for (int idx = tid; idx < 3 * HB * HB; idx += 384) {
+    for (int idx = tid; idx < 3 * HB * HB; idx += B3_NT) {
         const int c = idx >> 12, ij = idx & 4095;
         G[c][ij >> 6][ij & 63] = gh[((long long)n * 3 + c) * HB * HB + ij];
     }
-    const int c = wave >> 1, prod = wave & 1;
-    // (u, v) of component c in terms of the shared rows: array index, mirrored?, sign of the coordinate
+    const int c = wave >> 2, prod = (wave >> 1) & 1, rt = wave & 1;
+    // (u, v) of component c in terms of the shared rows: array index, mirrored?
     const int ua = c == 2 ? 1 : 0, va = c == 0 ? 1 : 2;
     const bool um = c != 0, vm = c == 2;
-    const int ra = prod == 0 ? va : ua, oa = prod == 0 ? ua : va;          // Rhs row set / the row set the result is paired with
+    const int ra = prod == 0 ? va : ua, oa = prod == 0 ? ua : va;          // right-hand rows / the rows the result is paired with
     const bool rm = prod == 0 ? vm : um, om = prod == 0 ? um : vm;
     const float osign = om ? -1.f : 1.f;
-    const int pcol = lane & 31, hk = lane >> 5;
+    const int li = lane & 31, hk = lane >> 5;
+    const int row = rt * 32 + li;
+    float dcen[16];                                          // bin centres of this lane's 16 result rows
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dcen[e] = hist_center(rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk);
     for (int p0 = q0; p0 < q1; p0 += B3_PB) {
         __syncthreads();
         if (tid < B3_PB) {
@@ -490,51 +503,58 @@ __global__ __launch_bounds__(384) void rgbuv_hist_bwd3_kernel(int H, int W, TVie
             sx[tid][0] = x[0]; sx[tid][1] = x[1]; sx[tid][2] = x[2];
         }
         __syncthreads();
-        for (int idx = tid; idx < 3 * HB * B3_PB; idx += 384) {
+        for (int idx = tid; idx < 3 * HB * B3_PB; idx += B3_NT) {
             const int r = idx / (HB * B3_PB), rem = idx - r * (HB * B3_PB);
             const int i = rem / B3_PB, p = rem - i * B3_PB;
             K3[r][i][p] = iq_kernel(sco[r][p] - hist_center(i));
         }
         __syncthreads();
-        const float cval = osign * sco[oa][pcol];          // u or v of this component at the lane's pixel
-        float part0 = 0.f, part1 = 0.f;
         f32x16 acc[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 #pragma unroll 8
         for (int kk = 0; kk < HB / 2; ++kk) {
             const int k = 2 * kk + hk;
-            const int r0 = lane & 31, r1 = 32 + (lane & 31);
-            const float a0 = prod == 0 ? G[c][r0][k] : G[c][k][r0];
-            const float a1 = prod == 0 ? G[c][r1][k] : G[c][k][r1];
-            const float bv = K3[ra][rm ? 63 - k : k][pcol];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+            const float av = prod == 0 ? G[c][row][k] : G[c][k][row];
+            const float* br = K3[ra][rm ? 63 - k : k];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br[li], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br[32 + li], acc[1], 0, 0, 0);
         }
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int j = 0; j < 2; ++j) {
+            const int pcol = j * 32 + li;
+            const float cval = osign * sco[oa][pcol];    // u or v of this component at the lane's pixel
+            float s0 = 0.f, s1 = 0.f;                    // sum D k,  sum D k^2 (coord - d)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r2 = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
                 const float kq = K3[oa][om ? 63 - r2 : r2][pcol];
-                const float t = cval - hist_center(r2);
-                part0 += acc[rt][e] * kq;
-                part1 += acc[rt][e] * (-2.0f * t * INV_SIGMA2) * kq * kq;
+                const float w = acc[j][e] * kq;
+                s0 += w;
+                s1 = fmaf(w * kq, cval - dcen[e], s1);
             }
-        part0 += __shfl_xor(part0, 32, 64);
-        part1 += __shfl_xor(part1, 32, 64);
-        if (hk == 0) {
-            if (prod == 0) { r_diy[c][pcol] = part0; r_du[c][pcol] = siy[pcol] * part1; }
-            else { r_dv[c][pcol] = siy[pcol] * part1; }
+            s0 += __shfl_xor(s0, 32, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            if (hk == 0) {
+                // sum_rows D g(t) k^2 with g(t) = -2 (coord - d) / sigma^2
+                const float part1 = (-2.0f * INV_SIGMA2) * s1 * siy[pcol];
+                if (prod == 0) { racc[c][rt][0][pcol] = s0; racc[c][rt][1][pcol] = part1; }
+                else { racc[c][rt][2][pcol] = part1; }
+            }
         }
         __syncthreads();
         if (tid < B3_PB && p0 + tid < q1) {
-            const float du0 = r_du[0][tid], dv0 = r_dv[0][tid], du1 = r_du[1][tid], dv1 = r_dv[1][tid], du2 = r_du[2][tid], dv2 = r_dv[2][tid];
+            float diy = 0.f, du[3], dv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                diy += racc[k][0][0][tid] + racc[k][1][0][tid];
+                du[k] = racc[k][0][1][tid] + racc[k][1][1][tid];
+                dv[k] = racc[k][0][2][tid] + racc[k][1][2][tid];
+            }
             // u0 = lR - lG, v0 = lR - lB;  u1 = lG - lR, v1 = lG - lB;  u2 = lB - lR, v2 = lB - lG    (histogram.py:72-74)
-            const float dl[3] = {(du0 + dv0) - du1 - du2, (du1 + dv1) - du0 - dv2, (du2 + dv2) - dv0 - dv1};
-            const float diy = (r_diy[0][tid] + r_diy[1][tid]) + r_diy[2][tid];
+            const float dl[3] = {(du[0] + dv[0]) - du[1] - du[2], (du[1] + dv[1]) - du[0] - dv[2], (du[2] + dv[2]) - dv[0] - dv[1]};
             const float iy = siy[tid];
             float* o = dimg + ((long long)n * HW + p0 + tid) * 4;
 #pragma unroll
@@ -622,8 +642,15 @@ extern "C" int p2p_rgbuv_hist_hellinger_bwd3(int dtype, int N, int H, int W, con
     int rc = p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd3 prep");
     if (rc) return rc;
     int nsplit = 1;
-    while (N * nsplit < 512 && (H * W) / (nsplit * 2) >= 8 * B3_PB) nsplit *= 2;       // two workgroups per CU
-    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd3_kernel<T><<<dim3(N, nsplit), 384, 0, st>>>(H, W, make_view(fake), gh_ws, dimg, nsplit)));
+    while (N * nsplit < 256 && (H * W) / (nsplit * 2) >= 8 * B3_PB) nsplit *= 2;       // one 12-wave workgroup per CU
+    constexpr int SHM = (3 * HB * (HB + 1) + 3 * HB * B3_PB + 3 * B3_PB + B3_PB + 4 * B3_PB + 18 * B3_PB) * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)rgbuv_hist_bwd3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        (void)hipFuncSetAttribute((const void*)rgbuv_hist_bwd3_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        attr = true;
+    }
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd3_kernel<T><<<dim3(N, nsplit), B3_NT, SHM, st>>>(H, W, make_view(fake), gh_ws, dimg, nsplit)));
     return p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd3");
 }
 

@@ -147,7 +147,7 @@ def test_hellinger_loss_and_gradient_match_closed_form(size):
     assert np.count_nonzero(got3[..., 3]) == 0 and np.isfinite(got3).all()
     assert U.rel_err(got3, ref) < 2e-3
     assert np.linalg.norm(got3 - ref) / np.linalg.norm(ref) < 2e-3
-    assert np.linalg.norm(got3 - got) / np.linalg.norm(got) < 2e-5          # against the per-component form: f32 summation order only
+    assert np.linalg.norm(got3 - got) / np.linalg.norm(got) < 1e-4          # against the per-component form: f32 summation order only
 
 
 def test_histogram_model_train_step_matches_oracle():
