@@ -144,8 +144,14 @@ def lib():
     return _lib
 
 
+_fns = {}
+
+
 def call(name, *args):
-    rc = getattr(lib(), name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    rc = fn(*args)
     if rc != 0:
         raise P2PError(f"{name} failed (rc={rc}): {lib().p2p_last_error().decode()}")
 

@@ -29,7 +29,15 @@ def _torch_dtype(dtype):
     return torch.float32 if dtype == L.F32 else torch.bfloat16
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_STREAM_DEVICE = [None]          # device index of the process's engine (one process per GPU)
+
+
 def _stream():
+    """the current HIP stream as a C pointer.  Asked ~110 times per train step: the raw query (no torch.cuda.Stream object) keeps
+    the host side of a batch-4 step (launch-bound: fit() at the reference's BATCH_SIZE) short."""
+    if _RAW_STREAM is not None and _STREAM_DEVICE[0] is not None:
+        return C.c_void_p(_RAW_STREAM(_STREAM_DEVICE[0]))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -74,10 +82,16 @@ class HaloBuf:
         self._flat = torch.zeros(numel + 256, dtype=_torch_dtype(dtype), device=device)
         self.t = self._flat[:numel].view(n, self.hp, self.wp, c)
         self.esz = self.t.element_size()
+        self._views = {}
 
     def view(self, coff=0, n0=0):
-        off = ((n0 * self.hp + HALO) * self.wp + HALO) * self.c + coff
-        return L.Tensor(self.t.data_ptr() + off * self.esz, self.hp * self.wp, self.wp, self.c)
+        """p2p_tensor of the interior (channel offset `coff`, first image `n0`); the descriptors are cached -- a step asks for
+        ~200 of them and the buffers never move"""
+        v = self._views.get((coff, n0))
+        if v is None:
+            off = ((n0 * self.hp + HALO) * self.wp + HALO) * self.c + coff
+            v = self._views[(coff, n0)] = L.Tensor(self.t.data_ptr() + off * self.esz, self.hp * self.wp, self.wp, self.c)
+        return v
 
 
 class DenseBuf:
@@ -87,10 +101,14 @@ class DenseBuf:
         self.n, self.h, self.w, self.c = n, h, w, c
         self.t = torch.empty((n * h * w, c), dtype=torch_dtype, device=device)
         self.esz = self.t.element_size()
+        self._views = {}
 
     def view(self, coff=0, n0=0):
-        return L.Tensor(self.t.data_ptr() + (n0 * self.h * self.w * self.c + coff) * self.esz,
-                        self.h * self.w, self.w, self.c)
+        v = self._views.get((coff, n0))
+        if v is None:
+            v = self._views[(coff, n0)] = L.Tensor(self.t.data_ptr() + (n0 * self.h * self.w * self.c + coff) * self.esz,
+                                                   self.h * self.w, self.w, self.c)
+        return v
 
     def ptr(self, n0=0):
         return C.c_void_p(self.t.data_ptr() + n0 * self.h * self.w * self.c * self.esz)
@@ -236,6 +254,8 @@ class Pix2PixEngine:
         self.in_ch, self.out_ch, self.head, self.S = in_ch, out_ch, head, img_size
         self.dtype, self.device, self.use_mfma = dtype, torch.device(device), use_mfma
         self.tdt = _torch_dtype(dtype)
+        if self.device.type == "cuda":
+            _STREAM_DEVICE[0] = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.G = ParamStore(generator_param_shapes(in_ch, out_ch), self.device)
         self.D = ParamStore(discriminator_param_shapes(in_ch), self.device)
         # one allocation [G gradients | D gradients | 16 loss slots]: under data parallelism the generator's small-tensor
