@@ -91,6 +91,55 @@ def test_loading_one_network_leaves_the_other_and_both_optimizers_untouched(tmp_
         KW.import_model(b, both, which=("critic",))
 
 
+def test_event_records_parse_with_an_independent_protobuf_runtime(tmp_path):
+    """the event file was only ever read by its own reader.  Here the serialized `Event` messages are
+    parsed by google.protobuf from a schema declared field by field (tensorflow/core/util/event.proto and
+    framework/summary.proto: Event.wall_time = 1 double, step = 2 int64, file_version = 3 string, summary = 5; Summary.value =
+    1 repeated; Value.tag = 1 string, simple_value = 2 float), the TFRecord framing is taken apart by hand and its
+    CRC-32C (Castagnoli) is checked against the algorithm's published check values."""
+    pytest.importorskip("google.protobuf")
+    import struct
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="p2p_event.proto", package="p2ptest", syntax="proto3")
+    val = fd.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=descriptor_pb2.FieldDescriptorProto.TYPE_STRING, label=1)
+    val.field.add(name="simple_value", number=2, type=descriptor_pb2.FieldDescriptorProto.TYPE_FLOAT, label=1)
+    summ = fd.message_type.add(name="Summary")
+    summ.field.add(name="value", number=1, type=descriptor_pb2.FieldDescriptorProto.TYPE_MESSAGE, label=3, type_name=".p2ptest.Value")
+    ev = fd.message_type.add(name="Event")
+    ev.field.add(name="wall_time", number=1, type=descriptor_pb2.FieldDescriptorProto.TYPE_DOUBLE, label=1)
+    ev.field.add(name="step", number=2, type=descriptor_pb2.FieldDescriptorProto.TYPE_INT64, label=1)
+    ev.field.add(name="file_version", number=3, type=descriptor_pb2.FieldDescriptorProto.TYPE_STRING, label=1)
+    ev.field.add(name="summary", number=5, type=descriptor_pb2.FieldDescriptorProto.TYPE_MESSAGE, label=1, type_name=".p2ptest.Summary")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("p2ptest.Event"))
+    # CRC-32C known answers (RFC 3720 B.4 / the iSCSI check value)
+    assert tb_events.crc32c(b"123456789") == 0xE3069283
+    assert tb_events.crc32c(bytes(32)) == 0x8A9136AA and tb_events.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    w = tb_events.EventFileWriter(str(tmp_path))
+    rows = [("generator/total_loss", 1.5, 0, 100.25), ("l1-evaluation/test", 0.0625, 7, 101.5), ("discriminator/fake_loss", -2.0, 2 ** 40, 102.0)]
+    w.add_scalars(rows)
+    data = open(w.path, "rb").read()
+    pos, events = 0, []
+    while pos < len(data):
+        (ln,) = struct.unpack_from("<Q", data, pos)
+        body = data[pos + 12:pos + 12 + ln]
+        for blob, at in ((data[pos:pos + 8], pos + 8), (body, pos + 12 + ln)):       # masked crc: rotate right 15, add the constant
+            c = tb_events.crc32c(blob)
+            assert struct.unpack_from("<I", data, at)[0] == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+        m = Event()
+        m.ParseFromString(body)
+        events.append(m)
+        pos += 16 + ln
+    assert events[0].file_version == "brain.Event:2" and len(events) == 1 + len(rows)
+    for m, (tag, value, step, wall) in zip(events[1:], rows):
+        assert m.step == step and m.wall_time == wall and len(m.summary.value) == 1
+        assert m.summary.value[0].tag == tag and m.summary.value[0].simple_value == value
+        if step:        # (proto3 omits a zero step on re-serialisation; the writer emits it explicitly -- both decode to 0)
+            assert m.SerializeToString() == tb_events.encode_event(wall, step=step, scalars=[(tag, value)])     # canonical encoding
+
+
 def test_palette_extraction_and_index_round_trip_are_bit_exact():
     rng = np.random.default_rng(7)
     colours = np.array([[0, 0, 0, 0], [10, 20, 30, 255], [200, 10, 10, 255], [10, 200, 10, 255], [250, 250, 250, 255],
