@@ -8,7 +8,7 @@
     size-independent property (per-image histograms, Hellinger recomputed from them).
   * bf16 storage mode against f32 mode over a TRAJECTORY: same initial weights, same batches, same dropout masks (the device
     RNG is keyed by seed, step and element, not by dtype), 300 Adam steps at B = 4 -- smoothed L1 and discriminator-loss
-    curves within a stated band.
+    curves within a stated band (2 % / 3 %; measured 0.03 % / 0.14 %).
 Measured values are written to gpurun_out/parity_evidence.json (merged back by gpurun) and quoted in DESIGN.md section 2."""
 import json
 import os
@@ -160,7 +160,8 @@ def test_bf16_mode_trains_like_f32_mode_over_300_steps():
         "first_step_rel_diff": (np.abs(curves["bf16"][0] - curves["f32"][0]) / np.maximum(np.abs(curves["f32"][0]), 1e-9)).tolist()})
     # training makes progress in both modes, and by the same amount
     assert l1_f[-1] < 0.6 * l1_f[0] and l1_b[-1] < 0.6 * l1_b[0], (l1_f[0], l1_f[-1], l1_b[0], l1_b[-1])
-    assert abs(l1_b[-1] - l1_f[-1]) <= 0.15 * l1_f[-1], (l1_b[-1], l1_f[-1])
-    # band: the 50-step means of the two modes never differ by more than 15 % (L1) / 20 % (discriminator loss) of the f32 mean
-    assert l1_gap <= 0.15, l1_gap
-    assert d_gap <= 0.20, d_gap
+    assert abs(l1_b[-1] - l1_f[-1]) <= 0.02 * l1_f[-1], (l1_b[-1], l1_f[-1])
+    # band: the 50-step means of the two modes never differ by more than 2 % (L1) / 3 % (discriminator loss) of the f32 mean
+    # (measured on MI355X: 0.03 % and 0.14 %; L1 0.440 -> 0.2085 in both modes)
+    assert l1_gap <= 0.02, l1_gap
+    assert d_gap <= 0.03, d_gap
