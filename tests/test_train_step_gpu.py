@@ -189,6 +189,42 @@ def test_adam_fused_with_the_weight_copies_equals_the_two_launch_form(dtype):
     assert torch.equal(lw.wt.view(16, lw.cd, lw.cg), w.transpose(1, 2).to(lw.wt.dtype))
 
 
+@pytest.mark.parametrize("kind", ["baseline", "histogram", "indexed"])
+def test_host_side_step_replay_is_bit_identical_to_eager_launching(kind):
+    """Batch-4 steps are launch-bound; from the third step of a kind on the engine re-issues the recorded call list (same
+    kernels, order, streams; batch pointers and result tensor behind re-usable slots).  Six steps over changing batches, an
+    evaluation call in between: weights, Adam state and every loss must equal the eager engine's bit for bit."""
+    from palette_and_histo_gan_amd import dataset_utils as DU
+    B, S = 4, 64
+    if kind == "indexed":
+        batches = list(DU.synthetic_indexed_ds(24, batch_size=B, seed=3))
+    else:
+        batches = list(DU.synthetic_rgba_ds(24, batch_size=B, palette_size=24, seed=3))
+    runs = []
+    for replay in (True, False):
+        eng = E.Pix2PixEngine(1, 256, "softmax", S, L.BF16, seed=5) if kind == "indexed" else E.Pix2PixEngine(4, 4, "tanh", S, L.BF16, seed=5)
+        eng.replay_enabled = replay
+        losses = []
+        for t, b in enumerate(batches):
+            if kind == "indexed":
+                losses.append(eng.train_step_indexed(b[0], b[1], 0.01))
+            else:
+                losses.append(eng.train_step_rgba(b[0], b[1], 30.0, lambda_hist=1.0 if kind == "histogram" else None))
+            if t == 3:        # an evaluation between train steps uses the same buffers and must not disturb the recorded list
+                (eng.generate_indexed(b[0]) if kind == "indexed" else eng.generate(b[0]))
+        torch.cuda.synchronize()
+        assert len(eng._replays) == (1 if replay else 0)
+        runs.append((torch.stack(losses).cpu(), eng))
+    (la, a), (lb, b) = runs
+    assert torch.equal(la, lb), (la - lb).abs().max()
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        assert sa.t == sb.t == len(batches) and int(sa.t_dev[0]) == len(batches)
+        for buf in ("params", "m", "v"):
+            assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
+    assert a.step_count == b.step_count == len(batches)
+    assert int(a.mask_counter_dev[0]) == int(b.mask_counter_dev[0])
+
+
 def test_generate_is_forward_of_train_step():
     B, S = 2, 64
     rng, Gp, Dp, src, tgt, masks = setup_case(B, S, 23)
