@@ -323,12 +323,6 @@ class Pix2PixEngine:
         self._adam_head_ev = None
         self.side = _SideStream(self.device, overlap_wgrad)
         self.side_hist = _SideStream(self.device, overlap_wgrad)     # third stream: histogram-loss chain
-        # Adam per layer, on a stream of its own, as soon as that layer's weight gradient is complete (single GPU): the optimizer's
-        # 0.82 GB of traffic leaves the end of the main stream (where it costs its full 0.14 ms) and runs beside the MFMA kernels
-        # of the backward pass.  bf16 only: in f32 mode the masters are themselves MFMA operands of the data gradients.
-        self.side_adam = _SideStream(self.device, overlap_wgrad)
-        self.layer_adam = int(os.environ.get("P2P_LAYER_ADAM", "1"))
-        self._layer_adam_on = False
         self._dp = None             # parallel.DataParallel of the step in flight
         self._batch_offset = 0      # samples of the global batch in front of this rank's shard (keys the dropout stream)
         self.use_conv_fewout = os.environ.get("P2P_CONV_FEWOUT", "1") != "0"    # 1..4-output heads: tap-major GEMM + shifted sum
@@ -729,14 +723,6 @@ class Pix2PixEngine:
         self.side.fork()
         with self.side.run():
             self._wgrad_impl(P, sid, name, N, lh, hi, lo, stride, dbias)
-            if self._layer_adam_on:
-                done = _record_event()                  # this layer's dW is complete on the weight-gradient stream
-                store = self._store(sid)
-                off, n = store.offsets[name + ".kernel"], int(np.prod(store.shapes[name + ".kernel"]))
-                with self.side_adam.run():
-                    _wait_event(done)                   # (also orders the step-size tick of _early_side in front of us)
-                    L.call("p2p_adam_flat_dev", _p(store.params, off), _p(store.grads, off), _p(store.m, off), _p(store.v, off), n,
-                           _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
             dp = self._dp
             if dp is None and sid == "G" and self.side.enabled and len(self.G.buckets) >= 2 \
                     and self.G.bucket_last_layer[len(self.G.buckets) - 2] == name:
@@ -860,7 +846,7 @@ class Pix2PixEngine:
             return None
         return (kind, B, self.side.enabled, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
                 self.hist_points, self.fuse_act_bwd, self.split_prep, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
-                self.use_mfma, self.layer_adam) + extra
+                self.use_mfma) + extra
 
     def _bind_batch(self, src_t, real_t):
         """the batch tensors of this step behind the re-usable pointer slots the recorded calls hold"""
@@ -933,9 +919,6 @@ class Pix2PixEngine:
                 for store in (self.G, self.D):
                     L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
                 self._ticked = True
-            # per-layer Adam needs this step's step size on the device before the first weight gradient (the ticks above)
-            self._layer_adam_on = bool(self.layer_adam and apply_update and self._dp is None and self.dtype == L.BF16 and
-                                       self.use_mfma and self.side.enabled and self.side_adam.enabled and not self.fuse_adam)
             P["early_masks"] = masks is None
             P["early_ev"] = None
             if self.side.enabled:
@@ -1211,8 +1194,6 @@ class Pix2PixEngine:
         are already complete -- everything in front of the last bucket, 90 % of the parameters -- runs in that window: a
         memory-bound kernel next to the compute-bound tail of the other stream.  Returns the first element still to update."""
         ev, self._adam_head_ev = self._adam_head_ev, None
-        if self._layer_adam_on:
-            return 0
         if not apply_update or not self._ticked or len(self.G.buckets) < 2:
             return 0
         if self._dp is not None:
@@ -1242,19 +1223,6 @@ class Pix2PixEngine:
         """Both optimizers step with gradients taken at the same pre-update weights (pix2pix_model.py:81-83).  `g_from`:
         first generator element not yet updated by _adam_head."""
         ticked, self._ticked = self._ticked, False      # counters already advanced by _early_side of this step
-        if self._layer_adam_on:
-            # every kernel tensor was updated behind its weight gradient; what is left: gamma / beta / bias and the operand copies
-            self._layer_adam_on = False
-            self.side_adam.join()
-            for store in (self.G, self.D):
-                store.t += 1
-                lo_e, hi_e = store.small_range
-                if hi_e > lo_e:
-                    L.call("p2p_adam_flat_dev", _p(store.params, lo_e), _p(store.grads, lo_e), _p(store.m, lo_e), _p(store.v, lo_e),
-                           hi_e - lo_e, _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
-            self._head_prepped = False
-            self.refresh_weight_copies("all")
-            return
         if self.fuse_adam:
             for store in (self.G, self.D):
                 store.t += 1
