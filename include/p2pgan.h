@@ -201,6 +201,15 @@ int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C,
                      const float* gamma, const float* beta, float eps, int act, float alpha,
                      const unsigned char* mask, const p2p_tensor* out, void* raw_out, float* stats,
                      float* ws, long long ws_bytes, int nsplit, void* stream);
+/* As p2p_norm_act_fwd, and copies tail_ch channels per pixel from the view `tail` (same N, H, W) into the channels that
+ * FOLLOW this layer's C channels in `out`: the last concat of the generator is [up6 | input image] (networks.py:92-94) and
+ * written this way every pixel of the concat buffer leaves one wave complete (no partial 32-byte sectors: the separate
+ * copy cost 41 of 71 us with cold caches).  Workgroup (vector) form only: H*W > 16, C % 8 == 0, tail_ch whole 16-byte vectors. */
+int p2p_norm_act_fwd_tail(int dtype, int N, int H, int W, int C,
+                          const void* raw, int raw_kind, int nslabs, long long slab_stride,
+                          const float* gamma, const float* beta, float eps, int act, float alpha,
+                          const unsigned char* mask, const p2p_tensor* out, void* raw_out, float* stats,
+                          float* ws, long long ws_bytes, int nsplit, const p2p_tensor* tail, int tail_ch, void* stream);
 
 /* Backward of the fused block: dact = g1 + g2 (pointwise gradient sources), through dropout/activation
  * (sign recomputed from raw+stats) and the InstanceNorm closed form.  Writes d(raw)
@@ -245,6 +254,10 @@ int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor
  * images in f32 in every mode (log-chroma of dark colours does not survive 8 significant bits). */
 int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* real,
                     const p2p_tensor* fake, float inv_count, float* partials, float* fake_f32, void* stream);
+/* The train step's form for 4-channel images whose discriminator inputs are 8-channel pixels [image | source]
+ * (networks.py:45): real_pair = [target | source] is read whole and the WHOLE fake pixel [tanh(z) | source] is written. */
+int p2p_tanh_l1_fwd_pair(int dtype, int N, int H, int W, const p2p_tensor* z, const p2p_tensor* real_pair,
+                         const p2p_tensor* fake_pair, float inv_count, float* partials, float* fake_f32, void* stream);
 
 /* dz = (g_d + g_extra + lambda_l1*inv_count*sign(fake-real)) * (1 - fake^2) into the haloed view dz. */
 int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
@@ -385,7 +398,9 @@ int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const void* src,
                          const p2p_tensor* dsts, int ndst, void* stream);
 /* The RGBA (4-channel) batch of a train step in one launch: source and target read once, whole-pixel stores into
  * down1's input [source|0], channels 32..39 of the last concat buffer [source|0], the real half of the discriminator
- * input [target|source] and the source half of its fake half.  Every view starts on an 8-channel boundary. */
+ * input [target|source] and the source half of its fake half.  Every view starts on an 8-channel boundary.
+ * v_c6 and v_dfake may be NULL: those two are PARTIAL-pixel stores (16 of 80 bytes, 8 of 16), which the train step leaves to
+ * the kernels that write the rest of the pixel (p2p_norm_act_fwd_tail, p2p_tanh_l1_fwd_pair). */
 int p2p_pack_pair(int dtype, int N, int H, int W, const float* source, const float* target,
                   const p2p_tensor* v_src, const p2p_tensor* v_c6, const p2p_tensor* v_dreal, const p2p_tensor* v_dfake,
                   void* stream);
@@ -417,6 +432,15 @@ int p2p_comm_unique_id(void* id_out_128_bytes);
 int p2p_comm_init(const void* id_128_bytes, int rank, int world, void** comm_out);
 int p2p_comm_allreduce_sum(void* comm, float* buf, long long n, void* stream);
 int p2p_comm_destroy(void* comm);
+
+/* ---- stream ordering (the drop-in's own schedule; the reference's train_step is one tf.function, pix2pix_model.py:63-87) ---
+ * Events that order kernels of ONE device between the engine's HIP streams (weight gradients and histograms run beside the
+ * data-gradient chain).  Created with hipEventDisableTiming | hipEventDisableSystemFence: no host-visible release, so a record
+ * does not write back / invalidate L2.  Not for host synchronisation (use the stream's own synchronise for that). */
+int p2p_event_create(void** ev_out);
+int p2p_event_destroy(void* ev);
+int p2p_event_record(void* ev, void* stream);            /* marks the work issued so far on `stream` */
+int p2p_stream_wait_event(void* stream, void* ev);       /* later work on `stream` waits for the event's latest record */
 
 /* ---- input pipeline (reference dataset_utils.py:11-20,39-49,66-120,209-246) ---------------------------- */
 

@@ -43,12 +43,14 @@ SIGNATURES = {
     "p2p_weight_prep_pad": [_i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "p2p_wgemm": [_i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp],
     "p2p_norm_act_fwd": [_i, _i, _i, _i, _i, _vp, _i, _i, _ll, _vp, _vp, _f, _i, _f, _vp, _TP, _vp, _vp, _vp, _ll, _i, _vp],
+    "p2p_norm_act_fwd_tail": [_i, _i, _i, _i, _i, _vp, _i, _i, _ll, _vp, _vp, _f, _i, _f, _vp, _TP, _vp, _vp, _vp, _ll, _i, _TP, _i, _vp],
     "p2p_norm_act_bwd": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _GP, _GP, _TP, _vp, _vp, _vp, _ll, _i, _vp],
     "p2p_colsum": [_vp, _i, _i, _f, _vp, _vp],
     "p2p_colsum_batched": [_vp, _vp, _i, _i, _vp, _vp],
     "p2p_bce_logits": [_i, _i, _i, _i, _i, _TP, _f, _TP, _TP, _vp, _vp],
     "p2p_loss_partials_sum": [_vp, _i, _vp, _vp],
     "p2p_tanh_l1_fwd": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp, _vp],
+    "p2p_tanh_l1_fwd_pair": [_i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp, _vp],
     "p2p_tanh_l1_bwd": [_i, _i, _i, _i, _i, _TP, _TP, _GP, _GP, _f, _TP, _vp],
     "p2p_adam_flat": [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp],
     "p2p_adam_tick": [_vp, _vp, _f, _f, _f, _vp],
@@ -80,6 +82,10 @@ SIGNATURES = {
     "p2p_comm_init": [_vp, _i, _i, C.POINTER(_vp)],
     "p2p_comm_allreduce_sum": [_vp, _vp, _ll, _vp],
     "p2p_comm_destroy": [_vp],
+    "p2p_event_create": [C.POINTER(_vp)],
+    "p2p_event_destroy": [_vp],
+    "p2p_event_record": [_vp, _vp],
+    "p2p_stream_wait_event": [_vp, _vp],
     "p2p_png_unfilter": [_vp, _i, _i, _i, _vp],
     "p2p_sprites_rgba_batch": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "p2p_gather_rows_i32": [_vp, _i, _i, _vp, _i, _vp, _vp],

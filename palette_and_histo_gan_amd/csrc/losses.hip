@@ -187,6 +187,56 @@ extern "C" int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_
     return p2p_check_launch("p2p_tanh_l1_fwd");
 }
 
+// The train step's form for 4-channel images whose discriminator inputs are 8-channel pixels [image | source]
+// (networks.py:45): `real_pair` = [target | source] is read as whole pixels and the WHOLE fake pixel [tanh(z) | source] is
+// written -- written as two halves by two kernels, the 8 of every 16 bytes were partial sector writes in both.
+template <typename T>
+__global__ __launch_bounds__(1024) void tanh_l1_fwd_pair_kernel(int N, PixDec dec, TView z, TView real, TView fake, float inv_count,
+                                                                float* __restrict__ partials, float* __restrict__ fake_f32) {
+    __shared__ float red[16];
+    typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+    typedef __attribute__((__vector_size__(8 * sizeof(T)))) T vec8_t;
+    const unsigned npix = (unsigned)N * dec.H * dec.W;
+    float acc = 0.f;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(p, n, y, x);
+        const vec4_t zv = *(const vec4_t*)((const T*)z.ptr + z.off(n, y, x));
+        const vec8_t rv = *(const vec8_t*)((const T*)real.ptr + real.off(n, y, x));
+        vec8_t fv;
+        f32x4 ff;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float t = tanhf(to_f32((T)zv[c]));
+            ff[c] = t;
+            T fq = from_f32<T>(t);
+            fv[c] = fq;
+            fv[4 + c] = rv[4 + c];
+            acc += fabsf(to_f32((T)rv[c]) - to_f32(fq));
+        }
+        *(vec8_t*)((T*)fake.ptr + fake.off(n, y, x)) = fv;
+        if (fake_f32) *(f32x4*)(fake_f32 + (long long)p * 4) = ff;      // unrounded copy for the histogram loss
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc * inv_count;
+}
+
+extern "C" int p2p_tanh_l1_fwd_pair(int dtype, int N, int H, int W, const p2p_tensor* z, const p2p_tensor* real_pair,
+                                    const p2p_tensor* fake_pair, float inv_count, float* partials, float* fake_f32, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0, "p2p_tanh_l1_fwd_pair: bad shape");
+    P2P_REQUIRE(z && z->ptr && real_pair && real_pair->ptr && fake_pair && fake_pair->ptr && partials, "p2p_tanh_l1_fwd_pair: null pointer");
+    P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_tanh_l1_fwd_pair: too many pixels");
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    P2P_REQUIRE(z->ld % 4 == 0 && ((uintptr_t)z->ptr % (4 * esz)) == 0, "p2p_tanh_l1_fwd_pair: z must be 4-channel aligned");
+    P2P_REQUIRE(real_pair->ld % 8 == 0 && fake_pair->ld % 8 == 0 && ((uintptr_t)real_pair->ptr % (8 * esz)) == 0 &&
+                    ((uintptr_t)fake_pair->ptr % (8 * esz)) == 0,
+                "p2p_tanh_l1_fwd_pair: the pair views must be whole 8-channel pixels");
+    P2P_DISPATCH_DTYPE(dtype, (tanh_l1_fwd_pair_kernel<T><<<dim3(P2P_LOSS_BLOCKS), 1024, 0, (hipStream_t)stream>>>(
+                                  N, PixDec::make(H, W), make_view(z), make_view(real_pair), make_view(fake_pair), inv_count, partials,
+                                  fake_f32)));
+    return p2p_check_launch("p2p_tanh_l1_fwd_pair");
+}
+
 extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
                                const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale, const p2p_tensor* dz,
                                void* stream) {

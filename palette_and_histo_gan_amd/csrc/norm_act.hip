@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
                                                         float eps, int act, float alpha,
                                                         const unsigned char* __restrict__ mask, TView out,
                                                         T* __restrict__ raw_out, float* __restrict__ stats,
-                                                        float* __restrict__ ws, int nslots) {
+                                                        float* __restrict__ ws, int nslots, TView tail, int tail_vecs) {
     constexpr int VN = VecOf<T>::N;
     __shared__ __attribute__((aligned(16))) float red[2][2048];      // [2][PR][CG], PR * CG = 256 * VN <= 2048
     const int n = blockIdx.x;
@@ -377,6 +377,16 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
         }
         int yy = p / W, xx = p - yy * W;
         vstore<T>((T*)out.ptr + out.off(n, yy, xx) + c, x);
+        // tail: the channels that follow this layer's slice in the concat buffer are copied by the lane that wrote the
+        // slice's last vector, so the pixel leaves the wave complete (no partially written 32-byte sectors in HBM)
+        if (tail_vecs && c + VN == C) {
+            const long long to = tail.off(n, yy, xx), oo = out.off(n, yy, xx) + C;
+            for (int t = 0; t < tail_vecs; ++t) {
+                float tv[VN];
+                vload<T>((const T*)tail.ptr + to + t * VN, tv);
+                vstore<T>((T*)out.ptr + oo + t * VN, tv);
+            }
+        }
     }
 }
 
@@ -761,10 +771,11 @@ __global__ void colsum_kernel(const float* __restrict__ part, int rows, int cols
 
 static inline int pick_cb(int C) { return C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1))))); }
 
-extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const void* raw, int raw_kind, int nslabs,
-                                long long slab_stride, const float* gamma, const float* beta, float eps, int act,
-                                float alpha, const unsigned char* mask, const p2p_tensor* out, void* raw_out,
-                                float* stats, float* ws, long long ws_bytes, int nsplit, void* stream) {
+static int norm_act_fwd_impl(int dtype, int N, int H, int W, int C, const void* raw, int raw_kind, int nslabs,
+                             long long slab_stride, const float* gamma, const float* beta, float eps, int act,
+                             float alpha, const unsigned char* mask, const p2p_tensor* out, void* raw_out,
+                             float* stats, float* ws, long long ws_bytes, int nsplit, const p2p_tensor* tail, int tail_ch,
+                             void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_norm_act_fwd: bad shape");
     P2P_REQUIRE(raw && out && out->ptr, "p2p_norm_act_fwd: null pointer");
     P2P_REQUIRE(raw_kind == 1 || (raw_kind == 2 && nslabs >= 1), "p2p_norm_act_fwd: bad raw_kind/nslabs");
@@ -773,6 +784,16 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
     const int esz = dtype == P2P_BF16 ? 2 : 4, vn = 16 / esz;
     const bool vec = C % vn == 0 && out->ld % vn == 0 && ((uintptr_t)out->ptr % 16) == 0 && ((uintptr_t)raw % 16) == 0 &&
                      (!raw_out || ((uintptr_t)raw_out % 16) == 0) && (raw_kind == 1 || slab_stride % 4 == 0) && C % 8 == 0;
+    const int tvecs = tail ? tail_ch / vn : 0;
+    TView tv = tail ? make_view(tail) : TView{};
+    if (tail) {
+        // the tail copy lives in the workgroup form only (the caller asks for it on wide maps: the last skip connection)
+        P2P_REQUIRE(tail->ptr && tail_ch > 0 && tail_ch % vn == 0 && tail->ld % vn == 0 && ((uintptr_t)tail->ptr % 16) == 0,
+                    "p2p_norm_act_fwd_tail: the tail must be whole 16-byte vectors");
+        int cgt = C > 64 ? 64 : C;
+        while (C % cgt) cgt -= vn;
+        P2P_REQUIRE(vec && H * W > 16 && 256 % (cgt / vn) == 0, "p2p_norm_act_fwd_tail: shape not served by the vector form");
+    }
     if (vec && H * W <= 16) {
         // small maps: lane groups with register-resident pixels (also when the conv epilogue produced statistics:
         // recomputing them from <= 64 pixels is cheaper than pooling the slots)
@@ -808,7 +829,7 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
                 dim3 grid3(N, C / CG, sp2);
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 3><<<grid3, 256, 0, st>>>(
                                               H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                              make_view(out), (T*)raw_out, stats, ws, nslots)));
+                                              make_view(out), (T*)raw_out, stats, ws, nslots, tv, tvecs)));
                 return p2p_check_launch("p2p_norm_act_fwd");
             }
             if (!ws || (long long)N * sp * C * 2 * 4 > ws_bytes) sp = gamma ? 1 : sp;
@@ -816,14 +837,14 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
             if (sp == 1 || !gamma) {
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 0><<<grid, 256, 0, st>>>(
                                               H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                              make_view(out), (T*)raw_out, stats, ws, 0)));
+                                              make_view(out), (T*)raw_out, stats, ws, 0, tv, tvecs)));
             } else {
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 1><<<grid, 256, 0, st>>>(
                                               H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                              make_view(out), (T*)raw_out, stats, ws, 0)));
+                                              make_view(out), (T*)raw_out, stats, ws, 0, tv, tvecs)));
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_fwd_vec<T, 2><<<grid, 256, 0, st>>>(
                                               H, W, C, CG, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
-                                              make_view(out), (T*)raw_out, stats, ws, 0)));
+                                              make_view(out), (T*)raw_out, stats, ws, 0, tv, tvecs)));
             }
             return p2p_check_launch("p2p_norm_act_fwd");
         }
@@ -835,6 +856,28 @@ extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const voi
                                   H, W, C, CB, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask,
                                   make_view(out), (T*)raw_out, stats)));
     return p2p_check_launch("p2p_norm_act_fwd");
+}
+
+extern "C" int p2p_norm_act_fwd(int dtype, int N, int H, int W, int C, const void* raw, int raw_kind, int nslabs,
+                                long long slab_stride, const float* gamma, const float* beta, float eps, int act,
+                                float alpha, const unsigned char* mask, const p2p_tensor* out, void* raw_out,
+                                float* stats, float* ws, long long ws_bytes, int nsplit, void* stream) {
+    return norm_act_fwd_impl(dtype, N, H, W, C, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask, out,
+                             raw_out, stats, ws, ws_bytes, nsplit, nullptr, 0, stream);
+}
+
+// As p2p_norm_act_fwd, and additionally copies `tail_ch` channels per pixel from `tail` (same N, H, W) into the channels that
+// FOLLOW this layer's C channels in `out` (networks.py:92-94: the last concat is [up6 | input image]) -- the whole pixel of the
+// concat buffer is written by one wave.  Written apart (the copy in p2p_pack_pair), the 16 of every 80 bytes were partial
+// sector writes: 41 us of a 71 us launch with cold caches at B = 256 (tools/ubench/pack_abl.py).
+extern "C" int p2p_norm_act_fwd_tail(int dtype, int N, int H, int W, int C, const void* raw, int raw_kind, int nslabs,
+                                     long long slab_stride, const float* gamma, const float* beta, float eps, int act,
+                                     float alpha, const unsigned char* mask, const p2p_tensor* out, void* raw_out,
+                                     float* stats, float* ws, long long ws_bytes, int nsplit, const p2p_tensor* tail,
+                                     int tail_ch, void* stream) {
+    P2P_REQUIRE(tail, "p2p_norm_act_fwd_tail: null tail");
+    return norm_act_fwd_impl(dtype, N, H, W, C, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, mask, out,
+                             raw_out, stats, ws, ws_bytes, nsplit, tail, tail_ch, stream);
 }
 
 extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const void* raw, const float* stats,

@@ -4,6 +4,7 @@
 // batch value contract dataset_utils.py:39-48,209-246.
 #include "p2p_common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
@@ -391,27 +392,31 @@ __global__ void pack_pair_kernel(int N, PixDec dec, const float* __restrict__ so
             ts[k] = from_f32<T>(t4[k]); ts[4 + k] = sq[k];
         }
         *(vec8_t*)((T*)v_src.ptr + v_src.off(n, y, x)) = sz;
-        *(vec8_t*)((T*)v_c6.ptr + v_c6.off(n, y, x)) = sz;
+        if (v_c6.ptr) *(vec8_t*)((T*)v_c6.ptr + v_c6.off(n, y, x)) = sz;
         *(vec8_t*)((T*)v_dreal.ptr + v_dreal.off(n, y, x)) = ts;
-        *(vec4_t*)((T*)v_dfake.ptr + v_dfake.off(n, y, x) + 4) = sq;
+        if (v_dfake.ptr) *(vec4_t*)((T*)v_dfake.ptr + v_dfake.off(n, y, x) + 4) = sq;
     }
 }
 
 extern "C" int p2p_pack_pair(int dtype, int N, int H, int W, const float* source, const float* target, const p2p_tensor* v_src,
                              const p2p_tensor* v_c6, const p2p_tensor* v_dreal, const p2p_tensor* v_dfake, void* stream) {
-    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && source && target && v_src && v_c6 && v_dreal && v_dfake, "p2p_pack_pair: bad args");
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && source && target && v_src && v_dreal, "p2p_pack_pair: bad args");
     P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_pack_pair: too many pixels");
     const int esz = dtype == P2P_BF16 ? 2 : 4;
+    // v_c6 / v_dfake may be NULL: those two stores are PARTIAL pixels (16 of 80 bytes, 8 of 16), and the train step leaves them
+    // to the kernels that write the rest of the pixel (p2p_norm_act_fwd_tail, p2p_tanh_l1_fwd_pair)
     const p2p_tensor* vs[4] = {v_src, v_c6, v_dreal, v_dfake};
     for (int k = 0; k < 4; ++k)
-        P2P_REQUIRE(vs[k]->ptr && vs[k]->ld % 8 == 0 && ((uintptr_t)vs[k]->ptr % (8 * esz)) == 0,
+        P2P_REQUIRE(!vs[k] || (vs[k]->ptr && vs[k]->ld % 8 == 0 && ((uintptr_t)vs[k]->ptr % (8 * esz)) == 0),
                     "p2p_pack_pair: views must start on an 8-channel boundary (whole 16/32-byte pixels)");
+    TView none;
+    none.ptr = nullptr; none.img = 0; none.row = 0; none.ld = 0;
+    const TView vc = v_c6 ? make_view(v_c6) : none, vd = v_dfake ? make_view(v_dfake) : none;
     P2P_REQUIRE(((uintptr_t)source % 16) == 0 && ((uintptr_t)target % 16) == 0, "p2p_pack_pair: batches must be 16-byte aligned");
     long long blocks = ((long long)N * H * W + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     P2P_DISPATCH_DTYPE(dtype, (pack_pair_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
-                                  N, PixDec::make(H, W), source, target, make_view(v_src), make_view(v_c6), make_view(v_dreal),
-                                  make_view(v_dfake))));
+                                  N, PixDec::make(H, W), source, target, make_view(v_src), vc, make_view(v_dreal), vd)));
     return p2p_check_launch("p2p_pack_pair");
 }
 

@@ -42,7 +42,8 @@ __device__ __forceinline__ void glds16s(const char* g, char* l) {
 __device__ __forceinline__ int ws_swz(int b, int m) { return b ^ (((b >> 8) & m) << 6); }
 
 template <typename T, int S, int GT, int DT, int TPW>
-__global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
+__global__ __launch_bounds__(1024 / TPW) __attribute__((amdgpu_waves_per_eu(TPW == 2 && GT * DT <= 2 ? 4 : 2)))
+void wgrad_small_kernel(WsArgs a) {   // 8-wave variants with <= 2 tiles per tap: two workgroups per CU (<= 128 VGPRs)
     constexpr int NTHR = 1024 / TPW;                 // TPW taps per wave: 8 waves (TPW = 2) or 16 waves (TPW = 1)
     constexpr int ESZ = sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,6 +80,26 @@ __global__ __launch_bounds__(1024 / TPW) void wgrad_small_kernel(WsArgs a) {
         const int n = strip / a.strips_per_img, y0 = (strip % a.strips_per_img) * TH;
         // ---- the hi strip (rows s*y0-1 .. , columns -1 ..) and the lo strip, 16 bytes per lane -----------------
         const int hchunks_row = hrowB >> 4, hchunks = RH * hchunks_row, hcpp = hpB >> 4;
+        if (a.pack) {
+            // Packed (few-channel) layers stage whole pixels without a swizzle: a strip row in LDS is a verbatim copy of a
+            // contiguous run of HBM bytes.  Rows are dealt to the waves; the row base is wave-uniform (scalar registers) and a
+            // lane only adds its 16-byte slot -- no per-slot integer divisions (they bounded these layers' staging, r03).
+            constexpr int NWV = NTHR / 64;
+            const int LWq = a.pack == 2 ? TW + 3 : TW, LHq = a.pack == 2 ? TH + 3 : TH, org = a.pack == 2 ? -2 : 0;
+            const int lcr = (LWq * lpB) >> 4;
+            const char* hrow0 = a.hi + ((long long)n * a.hi_img + (long long)(S * y0 - 1) * a.hi_row - 1) * hgB;
+            const char* lrow0 = a.lo + ((long long)n * a.lo_img + (long long)(y0 + org) * a.lo_row + org) * lgB;
+            for (int r = wave; r < RH + LHq; r += NWV) {
+                const bool isHi = r < RH;
+                const int rr = isHi ? r : r - RH;
+                const int cpr = isHi ? hchunks_row : lcr;
+                const char* src = isHi ? hrow0 + (long long)rr * a.hi_row * hgB : lrow0 + (long long)rr * a.lo_row * lgB;
+                char* dst = (isHi ? hiB : loB) + rr * cpr * 16;
+                for (int c0 = 0; c0 < cpr; c0 += 64)
+                    if (c0 + lane < cpr) glds16s(src + (c0 + lane) * 16, dst + c0 * 16);
+            }
+            return;
+        }
         for (int cI = wave * 64; cI < hchunks; cI += NTHR) {
             int ci = cI + lane;
             if (ci < hchunks) {

@@ -66,6 +66,40 @@ def _op(fn):
         _REC[0].append((None, fn, None))
 
 
+LIGHT_EVENTS = os.environ.get("P2P_LIGHT_EVENTS", "1") != "0"     # 0: torch.cuda.Event (system-scope release on every record)
+_EVENT_RING, _EVENT_NEXT = [], [0]
+_EVENT_RING_SIZE = 512            # far more than the stream operations of one step: an event is long consumed when its turn comes again
+
+
+def _ring_event():
+    """the next device-only ordering event (p2p_event_create: no timing, no system fence) of a small ring"""
+    i = _EVENT_NEXT[0]
+    _EVENT_NEXT[0] = (i + 1) % _EVENT_RING_SIZE
+    if i >= len(_EVENT_RING):
+        ev = C.c_void_p()
+        L.call("p2p_event_create", C.byref(ev))
+        _EVENT_RING.append(ev)
+    return _EVENT_RING[i]
+
+
+def _raw(stream):
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _order(after, before):
+    """work issued to stream `after` from now on waits for everything issued so far on stream `before`"""
+    if not LIGHT_EVENTS:
+        _op(lambda: after.wait_stream(before))
+        return
+    ev, a, b = _ring_event(), _raw(after), _raw(before)
+    rec, wait = L.lib().p2p_event_record, L.lib().p2p_stream_wait_event
+
+    def go():
+        if rec(ev, b) != 0 or wait(a, ev) != 0:
+            raise L.P2PError("stream ordering failed: " + L.lib().p2p_last_error().decode())
+    _op(go)
+
+
 class _SideStream:
     """Fork/join helper: weight-gradient GEMMs only feed Adam, so they run on a second HIP stream concurrently with
     the data-gradient chain (the critical path of the backward pass).  fork() makes the side stream wait for
@@ -77,28 +111,51 @@ class _SideStream:
 
     def fork(self):
         if self.enabled:
-            cur, side = torch.cuda.current_stream(), self.stream
-            _op(lambda: side.wait_stream(cur))
+            _order(self.stream, torch.cuda.current_stream())
 
     def run(self):
         return torch.cuda.stream(self.stream) if self.enabled else _NullCtx()
 
     def join(self):
         if self.enabled:
-            cur, side = torch.cuda.current_stream(), self.stream
-            _op(lambda: cur.wait_stream(side))
+            _order(torch.cuda.current_stream(), self.stream)
+
+
+class _TorchEvent:
+    def __init__(self, st):
+        self.ev = torch.cuda.Event()
+        _op(lambda: self.ev.record(st))
+
+    def wait(self, st):
+        _op(lambda: st.wait_event(self.ev))
+
+
+class _LightEvent:
+    def __init__(self, st):
+        self.ev = _ring_event()
+        ev, s, rec = self.ev, _raw(st), L.lib().p2p_event_record
+
+        def go():
+            if rec(ev, s) != 0:
+                raise L.P2PError("event record failed: " + L.lib().p2p_last_error().decode())
+        _op(go)
+
+    def wait(self, st):
+        ev, s, wait = self.ev, _raw(st), L.lib().p2p_stream_wait_event
+
+        def go():
+            if wait(s, ev) != 0:
+                raise L.P2PError("event wait failed: " + L.lib().p2p_last_error().decode())
+        _op(go)
 
 
 def _record_event():
     """a new event recorded on the current stream (replayable)"""
-    ev, st = torch.cuda.Event(), torch.cuda.current_stream()
-    _op(lambda: ev.record(st))
-    return ev
+    return (_LightEvent if LIGHT_EVENTS else _TorchEvent)(torch.cuda.current_stream())
 
 
 def _wait_event(ev):
-    st = torch.cuda.current_stream()
-    _op(lambda: st.wait_event(ev))
+    ev.wait(torch.cuda.current_stream())
 
 
 class _NullCtx:
@@ -332,6 +389,9 @@ class Pix2PixEngine:
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self._prep_table = {}
         self._head_prepped = False
+        # partial-pixel stores (the source channels of the last concat buffer, the halves of the discriminator's fake pixel) are
+        # issued by the kernel that writes the rest of the pixel (0: separate stores in p2p_pack_pair, the r02 form)
+        self.full_pixels = os.environ.get("P2P_FULL_PIXELS", "1") != "0"
         self.fuse_act_bwd = int(os.environ.get("P2P_FUSE_ACT_BWD", "1"))   # D.last data gradient + LeakyReLU backward in one launch
         # Adam emitting the operand copies of the weights it updates (one pass, p2p_adam_prep_batched): measured 0.198 ms against
         # 0.187 ms for the flat Adam + batched copy launch on c2 (the tiled kernel streams slower than the flat one): off
@@ -717,6 +777,18 @@ class Pix2PixEngine:
                self.G.p(name + ".gamma"), self.G.p(name + ".beta"), IN_EPS, act, LEAKY_ALPHA, C.byref(out_view), _p(stats), _stream())
         return True
 
+    def _c6_tail(self, P):
+        """True where up6's normalisation launch also writes the source channels of the last concat buffer
+        (p2p_norm_act_fwd_tail: whole 80-byte pixels from one wave) and the packers leave them alone."""
+        key = ("c6_tail", self.full_pixels)
+        if key not in P:
+            lw, S = self.W[("G", "up6")], self.S
+            fused = (not UP_DROPOUT[5]) and self.use_mfma and lw.main and \
+                bool(L.lib().p2p_igemm_norm_act_ok(L.OP_P, self.dtype, P["B"], S // 2, S // 2, lw.cg, lw.cd))
+            P[key] = bool(self.full_pixels and not fused and self.src_ch == 8 and P["c"][6].c == UP_FILTERS[5] + 8
+                                and UP_FILTERS[5] % 8 == 0 and S * S > 16)
+        return P[key]
+
     def _wgrad(self, P, sid, name, N, lh, hi, lo, stride=2, dbias=None):
         """dW (and dbias) of one layer, issued on the side stream: its inputs were produced on the main stream
         before this call (fork), its outputs are only read by Adam (join in _finish_step)."""
@@ -785,20 +857,24 @@ class Pix2PixEngine:
             sp *= 2
         return sp
 
-    def _norm_fwd(self, P, N, res, c, raw_buf, rk, gamma, beta, act, mask, out_view, stats):
+    def _norm_fwd(self, P, N, res, c, raw_buf, rk, gamma, beta, act, mask, out_view, stats, tail=None):
+        """tail: view whose src_ch channels are copied behind this layer's channels in out_view (see _c6_tail)"""
         raw_kind, nslabs = rk[0], rk[1]
         raw = raw_buf.ptr() if raw_kind == 1 else _p(P["slabs"])
         slab = N * res * res * c
+        entry, extra = "p2p_norm_act_fwd", ()
+        if tail is not None:
+            entry, extra = "p2p_norm_act_fwd_tail", (C.byref(tail), self.src_ch)
         if len(rk) == 3:      # statistics already produced by the conv epilogue: apply-only pass
-            L.call("p2p_norm_act_fwd", self.dtype, N, res, res, c, raw, 1, 1, 0, gamma, beta, IN_EPS, act, LEAKY_ALPHA,
+            L.call(entry, self.dtype, N, res, res, c, raw, 1, 1, 0, gamma, beta, IN_EPS, act, LEAKY_ALPHA,
                    _p(mask) if mask is not None else NULL, C.byref(out_view), NULL, _p(stats),
-                   _p(P["spart"]), P["spart"].numel() * 4, -rk[2], _stream())
+                   _p(P["spart"]), P["spart"].numel() * 4, -rk[2], *extra, _stream())
             return
-        L.call("p2p_norm_act_fwd", self.dtype, N, res, res, c, raw, raw_kind, nslabs, slab,
+        L.call(entry, self.dtype, N, res, res, c, raw, raw_kind, nslabs, slab,
                gamma if gamma is not None else NULL, beta if beta is not None else NULL, IN_EPS, act, LEAKY_ALPHA,
                _p(mask) if mask is not None else NULL, C.byref(out_view),
                raw_buf.ptr() if raw_kind == 2 else NULL, _p(stats) if stats is not None else NULL,
-               _p(P["nws"]), P["nws"].numel() * 4, self._nsplit(N, res, c), _stream())
+               _p(P["nws"]), P["nws"].numel() * 4, self._nsplit(N, res, c), *extra, _stream())
 
     def _gs(self, P, buf, rk, coff=0):
         """gradient source for a conv result that went to `buf` (kind 1) or to the split-K slabs (kind 2)."""
@@ -845,7 +921,7 @@ class Pix2PixEngine:
                 or L.call is not _ORIG_CALL or not self.replay_enabled or torch.cuda.is_current_stream_capturing()):
             return None
         return (kind, B, self.side.enabled, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
-                self.hist_points, self.fuse_act_bwd, self.split_prep, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
+                self.hist_points, self.fuse_act_bwd, self.split_prep, self.full_pixels, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
                 self.use_mfma) + extra
 
     def _bind_batch(self, src_t, real_t):
@@ -897,7 +973,9 @@ class Pix2PixEngine:
         """the source image feeds down1, the last skip connection (networks.py:92) and, in a train step, the second half
         of both discriminator inputs (networks.py:45): one read, up to four writes"""
         ic, B = self.in_ch, P["B"]
-        views = [P["src"].view(), P["c"][6].view(coff=UP_FILTERS[5])]
+        views = [P["src"].view()]
+        if not self._c6_tail(P):
+            views.append(P["c"][6].view(coff=UP_FILTERS[5]))
         if with_disc:
             views += [P["dcat"].view(coff=ic), P["dcat"].view(coff=ic, n0=B)]
         self._pack_multi(P, src_t, views, ic, ptr=self._slot_src if src_t.data_ptr() == self._slot_src.value else None)
@@ -966,7 +1044,8 @@ class Pix2PixEngine:
                     L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self.seed, _p(self.mask_counter_dev), i,
                            self._batch_offset * (mask.numel() // B), _stream())
             self._norm_fwd(P, B, 2 * lh, f, P["ru"][i], rk, self.G.p(f"up{i}.gamma"), self.G.p(f"up{i}.beta"),
-                           L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i])
+                           L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i],
+                           tail=P["src"].view() if i == 6 and self._c6_tail(P) else None)
             lo_view = c[i].view()
         # head: Conv2D(out, 4, stride 1, SAME, bias) (networks.py:75-78)
         if head:
@@ -1036,11 +1115,12 @@ class Pix2PixEngine:
     def _train_step_rgba_body(self, P, B, Bg, src_t, real_t, lambda_l1, lambda_hist, masks, apply_update, dp):
         S, ic = self.S, self.in_ch
         self._bind_batch(src_t, real_t)
+        whole_fake = ic == 4 and self.src_ch == 8 and self.dcat_ch == 8 and self.full_pixels and self.out_ch == 4
         if ic == 4 and self.src_ch == 8 and self.dcat_ch == 8:
             # source and target in one launch, whole 16-byte pixels (networks.py:45,92-94)
             L.call("p2p_pack_pair", self.dtype, B, S, S, self._slot_src, self._slot_real, C.byref(P["src"].view()),
-                   C.byref(P["c"][6].view(coff=UP_FILTERS[5])), C.byref(P["dcat"].view(coff=0)),
-                   C.byref(P["dcat"].view(coff=0, n0=B)), _stream())
+                   None if self._c6_tail(P) else C.byref(P["c"][6].view(coff=UP_FILTERS[5])), C.byref(P["dcat"].view(coff=0)),
+                   None if whole_fake else C.byref(P["dcat"].view(coff=0, n0=B)), _stream())
         else:
             self._pack_source(P, src_t, with_disc=True)
             self._pack(P, real_t, P["dcat"].view(coff=0), ic, ptr=self._slot_real)
@@ -1052,9 +1132,14 @@ class Pix2PixEngine:
         inv_l1 = 1.0 / (Bg * S * S * self.out_ch)
         if lambda_hist is not None:
             self._hist_buffers(P, B)
-        L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
-               C.byref(fake_view), inv_l1, _p(self.loss_part, 3 * 256), _p(P["fake32"]) if lambda_hist is not None else NULL,
-               _stream())
+        if whole_fake:
+            # whole [fake | source] pixels (the source half comes from the real half's pixel)
+            L.call("p2p_tanh_l1_fwd_pair", self.dtype, B, S, S, C.byref(P["z"].view()), C.byref(real_view), C.byref(fake_view), inv_l1,
+                   _p(self.loss_part, 3 * 256), _p(P["fake32"]) if lambda_hist is not None else NULL, _stream())
+        else:
+            L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view),
+                   C.byref(fake_view), inv_l1, _p(self.loss_part, 3 * 256), _p(P["fake32"]) if lambda_hist is not None else NULL,
+                   _stream())
         g_extra = None
         if lambda_hist is not None:
             # the histogram loss only needs `fake`: its kernels (f32 MFMA, ~1.8 ms at B=256) run on the side stream,

@@ -43,6 +43,11 @@ def _ints(args, n):
     return [int(a) for a in args[:n]]
 
 
+def _null(a):
+    """a NULL pointer argument (None, or a ctypes pointer holding 0)"""
+    return a is None or (hasattr(a, "value") and not a.value)
+
+
 def _view_ld(byref_obj, default):
     """channel count of a pixel of a p2p_tensor passed with ctypes.byref"""
     t = getattr(byref_obj, "_obj", None)
@@ -98,13 +103,15 @@ def call_work(name, args, dtype):
     if name == "p2p_conv_direct":
         _, _, _, n, lh, lw, cg, cd = _ints(args, 8)
         return {"flops": 2.0 * n * lh * lw * 16 * cg * cd, "mfma": None, "bytes": 0.0}
-    if name == "p2p_norm_act_fwd":
+    if name in ("p2p_norm_act_fwd", "p2p_norm_act_fwd_tail"):
         _, n, h, w, c = _ints(args, 5)
         raw_kind, nslabs = int(args[6]), int(args[7])
         t = n * h * w * c
         by = t * (esz if raw_kind == 1 else 4 * nslabs) + t * esz
         if raw_kind == 2:
             by += t * esz                           # the folded raw tensor is written for the backward pass
+        if name == "p2p_norm_act_fwd_tail":
+            by += 2.0 * n * h * w * int(args[22]) * esz          # the tail channels: read + written
         return {"flops": 0.0, "mfma": None, "bytes": by}
     if name == "p2p_norm_act_bwd":
         _, n, h, w, c = _ints(args, 5)
@@ -157,7 +164,11 @@ def call_work(name, args, dtype):
         return {"flops": 0.0, "mfma": None, "bytes": (7 * 4.0 + 2 * esz) * int(args[1])}
     if name == "p2p_pack_pair":
         _, n, h, w = _ints(args, 4)
-        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2 * 4 * 4.0 + (8 + 4 + 8 + 4) * esz)}
+        ch = 8 + 8 + (0 if _null(args[7]) else 8) + (0 if _null(args[9]) else 4)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2 * 4 * 4.0 + ch * esz)}
+    if name == "p2p_tanh_l1_fwd_pair":          # z (4 ch) + [target | source] in, [fake | source] out (+ the f32 copy of fake)
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * ((4 + 8 + 8) * esz + (0.0 if _null(args[9]) else 16.0))}
     if name in ("p2p_tanh_l1_fwd", "p2p_tanh_l1_bwd"):
         _, n, h, w, c = _ints(args, 5)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * 3.0 * max(c, 8) * esz}

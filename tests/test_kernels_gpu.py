@@ -225,6 +225,70 @@ def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm, nsplit):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,c,nsplit,stats_mode", [(3, 8, 32, 1, False), (2, 32, 32, 4, False), (2, 16, 64, 1, False), (2, 8, 128, 1, False)])
+def test_norm_act_fwd_tail_writes_whole_concat_pixels(dtype, n, h, c, nsplit, stats_mode):
+    """p2p_norm_act_fwd_tail = p2p_norm_act_fwd + the copy of the following 8 channels from another view (the last concat of the
+    generator is [up6 | input image], networks.py:92-94): bit-identical to the two separate writes, halo untouched."""
+    rng = np.random.default_rng(31)
+    nws = torch.empty(n * 16 * c * 2, dtype=torch.float32, device=U.DEV)
+    x = U.q(rng.normal(size=(n, h, h, c)) * 2 + 0.3, dtype)
+    tail = U.q(rng.normal(size=(n, h, h, 8)), dtype)
+    gamma, beta = U.dev((1 + 0.2 * rng.normal(size=c)).astype(np.float32)), U.dev((0.2 * rng.normal(size=c)).astype(np.float32))
+    raw = E.DenseBuf(n, h, h, c, U.tdt(dtype), U.DEV)
+    raw.t.copy_(U.dev(x.reshape(-1, c), U.tdt(dtype)))
+    tb = U.halo_from(tail, dtype)
+    outs = []
+    for with_tail in (False, True):
+        out = E.HaloBuf(n, h, h, c + 8, dtype, U.DEV)
+        stats = torch.empty((n, c, 2), dtype=torch.float32, device=U.DEV)
+        args = (dtype, n, h, h, c, raw.ptr(), 1, 1, 0, U.ptr(gamma), U.ptr(beta), 1e-3, L.ACT_RELU, 0.3, None, C.byref(out.view(coff=0)),
+                None, U.ptr(stats), U.ptr(nws), nws.numel() * 4, nsplit)
+        if with_tail:
+            L.call("p2p_norm_act_fwd_tail", *args, C.byref(tb.view()), 8, U.stream())
+        else:
+            L.call("p2p_norm_act_fwd", *args, U.stream())
+            out.t[:, E.HALO:E.HALO + h, E.HALO:E.HALO + h, c:] = tb.t[:, E.HALO:E.HALO + h, E.HALO:E.HALO + h, :]
+        outs.append(out.t.clone())
+    assert torch.equal(outs[0], outs[1])
+    inner = outs[1][:, E.HALO:E.HALO + h, E.HALO:E.HALO + h, c:].float().cpu().numpy()
+    assert np.array_equal(inner, tail.astype(np.float32))
+    # small maps and ragged channel counts are refused, not silently served without the tail
+    out = E.HaloBuf(n, 4, 4, c + 8, dtype, U.DEV)
+    with pytest.raises(L.P2PError):
+        L.call("p2p_norm_act_fwd_tail", dtype, n, 4, 4, c, raw.ptr(), 1, 1, 0, U.ptr(gamma), U.ptr(beta), 1e-3, L.ACT_RELU, 0.3, None,
+               C.byref(out.view(coff=0)), None, U.ptr(stats), U.ptr(nws), nws.numel() * 4, 1, C.byref(tb.view()), 8, U.stream())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tanh_l1_fwd_pair_equals_the_two_partial_writes(dtype):
+    """p2p_tanh_l1_fwd_pair writes whole [tanh(z) | source] pixels of the discriminator's fake input (networks.py:45); the
+    4-channel form + a separate copy of the source half give the same buffer bit for bit, the same f32 copy and the same L1."""
+    rng = np.random.default_rng(32)
+    n, s = 3, 32
+    z = U.q(rng.normal(size=(n, s, s, 4)), dtype)
+    pair = U.q(rng.uniform(-1, 1, size=(n, s, s, 8)), dtype)           # [target | source]
+    zb, rb = U.halo_from(z, dtype), U.halo_from(pair, dtype)
+    inv = 1.0 / (n * s * s * 4)
+    res = []
+    for whole in (False, True):
+        fb = E.HaloBuf(n, s, s, 8, dtype, U.DEV)
+        part = torch.zeros(256, dtype=torch.float32, device=U.DEV)
+        f32copy = torch.empty((n, s, s, 4), dtype=torch.float32, device=U.DEV)
+        loss = torch.zeros(1, dtype=torch.float32, device=U.DEV)
+        if whole:
+            L.call("p2p_tanh_l1_fwd_pair", dtype, n, s, s, C.byref(zb.view()), C.byref(rb.view()), C.byref(fb.view()), inv, U.ptr(part),
+                   U.ptr(f32copy), U.stream())
+        else:
+            L.call("p2p_tanh_l1_fwd", dtype, n, s, s, 4, C.byref(zb.view()), C.byref(rb.view()), C.byref(fb.view()), inv, U.ptr(part),
+                   U.ptr(f32copy), U.stream())
+            fb.t[..., 4:] = rb.t[..., 4:]
+        L.call("p2p_loss_partials_sum", U.ptr(part), 1, U.ptr(loss), U.stream())
+        res.append((fb.t.clone(), f32copy.clone(), float(loss[0])))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert abs(res[0][2] - res[1][2]) <= 2e-6 * abs(res[0][2])          # same terms, another (fixed) summation order
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_losses(dtype):
     rng = np.random.default_rng(14)
     n2, nr, h = 6, 3, 8

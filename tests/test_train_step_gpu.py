@@ -154,6 +154,33 @@ def test_two_adam_steps_match_oracle_f32():
 
 
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+@pytest.mark.parametrize("hist", [False, True])
+def test_whole_pixel_stores_equal_the_partial_ones(dtype, hist):
+    """P2P_FULL_PIXELS: the source channels of the last concat buffer come from up6's normalisation launch and the fake half of
+    the discriminator input is written as whole [fake | source] pixels -- same bytes in the same buffers, so three steps give
+    the same weights bit for bit; only the L1 sum changes its (fixed) order."""
+    B, S = 3, 64
+    rng, Gp, Dp, src, tgt, masks = setup_case(B, S, seed=78)
+    engines, losses = [], []
+    for whole in (True, False):
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, dtype)
+        eng.full_pixels = whole
+        eng.set_params(to_np(Gp), to_np(Dp))
+        for _ in range(3):
+            out = eng.train_step_rgba(src, tgt, 100.0, lambda_hist=1.0 if hist else None, masks=masks)
+        torch.cuda.synchronize()
+        engines.append(eng)
+        losses.append(out.cpu().numpy())
+    a, b = engines
+    assert a._c6_tail(a.plan(B)) and not b._c6_tail(b.plan(B))
+    assert torch.equal(a.plan(B)["c"][6].t, b.plan(B)["c"][6].t) and torch.equal(a.plan(B)["dcat"].t, b.plan(B)["dcat"].t)
+    np.testing.assert_allclose(losses[0], losses[1], rtol=3e-6)
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        for buf in ("params", "m", "v"):
+            assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_adam_fused_with_the_weight_copies_equals_the_two_launch_form(dtype):
     """p2p_adam_prep_batched (Adam + operand copies in one pass) against p2p_adam_flat_dev followed by
     p2p_weight_prep_batched: same masters, moments and copies after three steps (the expressions are the same; the compiler
