@@ -361,6 +361,57 @@ __global__ __launch_bounds__(256) void norm_act_fwd_vec(int H, int W, int C, int
             }
         }
     }
+    if (raw_kind == 1 && !raw_out) {
+        // Dense input in the activation type (every launch of a bf16 step): U pixels per trip, every load of the trip issued
+        // before its first store and kept PACKED until used.  The output view may alias the inputs as far as the compiler
+        // knows, so the one-pixel loop below is "load, wait, store" with one 16-byte load in flight per lane.
+        typedef typename VecOf<T>::type vec_t;
+        constexpr int U = 4;
+        const bool do_tail = tail_vecs && c + VN == C;
+        for (int p0 = pb + pr; p0 < pe; p0 += PR * U) {
+            vec_t xr[U], tr[U];
+            unsigned long long mk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * PR;
+                if (p < pe) {
+                    const long long e = base + (long long)p * C;
+                    xr[u] = *(const vec_t*)((const T*)raw + e);
+                    if (mask) mk[u] = VN == 8 ? *(const unsigned long long*)(mask + e) : (unsigned long long)*(const unsigned*)(mask + e);
+                    if (do_tail) {
+                        const int yy = p / W, xx = p - yy * W;
+                        tr[u] = *(const vec_t*)((const T*)tail.ptr + tail.off(n, yy, xx));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * PR;
+                if (p >= pe) continue;
+                vec_t o;
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    const float xv = to_f32((T)xr[u][k]);
+                    float y = gamma ? (xv - mu[k]) * rs[k] * ga[k] + be[k] : xv;
+                    if (mask) y *= ((mk[u] >> (8 * k)) & 0xff) ? 2.f : 0.f;
+                    if (act == P2P_ACT_LEAKY) y = y > 0.f ? y : alpha * y;
+                    else if (act == P2P_ACT_RELU) y = y > 0.f ? y : 0.f;
+                    o[k] = from_f32<T>(y);
+                }
+                const int yy = p / W, xx = p - yy * W;
+                T* op = (T*)out.ptr + out.off(n, yy, xx);
+                *(vec_t*)(op + c) = o;
+                // tail: the channels that follow this layer's slice in the concat buffer are copied by the lane that wrote the
+                // slice's last vector, so the pixel leaves the wave complete (no partially written 32-byte sectors in HBM)
+                if (do_tail) {
+                    *(vec_t*)(op + C) = tr[u];
+                    for (int t = 1; t < tail_vecs; ++t)
+                        *(vec_t*)(op + C + t * VN) = *(const vec_t*)((const T*)tail.ptr + tail.off(n, yy, xx) + t * VN);
+                }
+            }
+        }
+        return;
+    }
     for (int p = pb + pr; p < pe; p += PR) {
         long long e = base + (long long)p * C;
         float x[VN], keep[VN];

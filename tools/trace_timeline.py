@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Reduces a rocprofv3 --kernel-trace CSV of bench.py to a per-step timeline summary: device busy time (union of kernel
 intervals), time with two or more kernels running, idle gaps, and per-kernel-family busy time.  Usage:
-  python tools/trace_timeline.py <dir with *_kernel_trace.csv> [first_step_marker_kernel]"""
+  python tools/trace_timeline.py <dir with *_kernel_trace.csv> [--list]
+--list additionally prints one whole step launch by launch: queue, start (us from the step's first launch), duration, idle time
+of that queue in front of the launch, kernel name -- the main stream's chain and the gaps the fork/join events leave in it."""
 import csv
 import glob
 import os
@@ -50,6 +52,18 @@ def main():
           f"launches {len(seg) / nsteps:.0f}/step, sum of kernel times {sum(fam.values()) / nsteps / 1e3:.1f} us/step")
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:25]:
         print(f"  {v / nsteps / 1e3:8.1f} us/step  {k}")
+    if "--list" in sys.argv:
+        a, b = starts[-3], starts[-2]
+        s0, last_end, gaps = rows[a][0], {}, defaultdict(float)
+        print("\none step, launch by launch (queue, start us, +duration us, queue idle before it, kernel):")
+        for s, e, n, q in rows[a:b + 1]:
+            gap = (s - last_end.get(q, s)) / 1e3
+            if q in last_end:
+                gaps[q] += max(gap, 0.0)
+            print(f"q{q} {(s - s0) / 1e3:8.1f} +{(e - s) / 1e3:7.1f}  gap {gap:6.1f}  {n.replace('void ', '').split('(')[0][:60]}")
+            last_end[q] = e
+        for q, g in sorted(gaps.items()):
+            print(f"queue {q}: idle between its launches {g:.1f} us")
 
 
 if __name__ == "__main__":
