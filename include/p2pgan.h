@@ -404,6 +404,12 @@ int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const void* src,
 int p2p_pack_pair(int dtype, int N, int H, int W, const float* source, const float* target,
                   const p2p_tensor* v_src, const p2p_tensor* v_c6, const p2p_tensor* v_dreal, const p2p_tensor* v_dfake,
                   void* stream);
+/* The palette-index batch of a train step (one int32 index per pixel, dataset_utils.py:232-246; 8-channel pixels): whole-pixel
+ * stores of [source 0..] into v_src (and v_c6 unless NULL), [target source 0..] into v_dreal, [0 source 0..] into v_dfake
+ * (its channel 0 is written later by the head's argmax). */
+int p2p_pack_pair_idx(int dtype, int N, int H, int W, const int* source, const int* target,
+                      const p2p_tensor* v_src, const p2p_tensor* v_c6, const p2p_tensor* v_dreal, const p2p_tensor* v_dfake,
+                      void* stream);
 /* out[7] = [g_total, g_adv, g_l1, g_aux, d_total, d_real, d_fake] from the loss slots written by the loss kernels:
  * slots[0..2] = BCE(1,real), BCE(0,fake), BCE(1,fake); slots[l1_slot] = L1; slots[aux_slot] = histogram /
  * segmentation loss (aux_slot < 0: none); g_total = adv + lambda_l1*l1 + lambda_aux*aux. */

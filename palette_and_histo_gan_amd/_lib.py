@@ -62,6 +62,7 @@ SIGNATURES = {
     "p2p_adam_prep_batched": [_i, _ll, _vp, _i, _ll, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp],
     "p2p_pack_input": [_i, _i, _i, _i, _i, _vp, _i, _TP, _vp],
     "p2p_pack_pair": [_i, _i, _i, _i, _vp, _vp, _TP, _TP, _TP, _TP, _vp],
+    "p2p_pack_pair_idx": [_i, _i, _i, _i, _vp, _vp, _TP, _TP, _TP, _TP, _vp],
     "p2p_pack_input_multi": [_i, _i, _i, _i, _i, _vp, _i, _TP, _i, _vp],
     "p2p_finish_losses": [_vp, _i, _i, _f, _f, _vp, _vp],
     "p2p_unpack": [_i, _i, _i, _i, _i, _TP, _vp, _vp],

@@ -420,6 +420,53 @@ extern "C" int p2p_pack_pair(int dtype, int N, int H, int W, const float* source
     return p2p_check_launch("p2p_pack_pair");
 }
 
+// The palette-index batch of a train step (Pix2PixIndexedModel: one int32 index per pixel, dataset_utils.py:232-246) in one
+// launch, WHOLE 8-channel pixels everywhere (a 2-byte store into a 16-byte pixel is a partial sector write):
+//   v_src   [source 0 0 0 0 0 0 0]      down1's input
+//   v_c6    the same pixel               channels 32..39 of the last concat buffer (NULL: left to p2p_norm_act_fwd_tail)
+//   v_dreal [target source 0 ...]        discriminator input, real half
+//   v_dfake [0      source 0 ...]        fake half: channel 0 is written later by the head (argmax)
+template <typename T>
+__global__ void pack_pair_idx_kernel(int N, PixDec dec, const int* __restrict__ source, const int* __restrict__ target, TView v_src,
+                                     TView v_c6, TView v_dreal, TView v_dfake) {
+    typedef __attribute__((__vector_size__(8 * sizeof(T)))) T vec8_t;
+    const unsigned npix = (unsigned)N * dec.H * dec.W;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        int n, y, x;
+        dec(p, n, y, x);
+        const T sq = from_f32<T>((float)source[p]), tq = from_f32<T>((float)target[p]), z = from_f32<T>(0.f);
+        vec8_t a, b, c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k] = z; b[k] = z; c[k] = z; }
+        a[0] = sq;
+        b[0] = tq; b[1] = sq;
+        c[1] = sq;
+        *(vec8_t*)((T*)v_src.ptr + v_src.off(n, y, x)) = a;
+        if (v_c6.ptr) *(vec8_t*)((T*)v_c6.ptr + v_c6.off(n, y, x)) = a;
+        *(vec8_t*)((T*)v_dreal.ptr + v_dreal.off(n, y, x)) = b;
+        *(vec8_t*)((T*)v_dfake.ptr + v_dfake.off(n, y, x)) = c;
+    }
+}
+
+extern "C" int p2p_pack_pair_idx(int dtype, int N, int H, int W, const int* source, const int* target, const p2p_tensor* v_src,
+                                 const p2p_tensor* v_c6, const p2p_tensor* v_dreal, const p2p_tensor* v_dfake, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && source && target && v_src && v_dreal && v_dfake, "p2p_pack_pair_idx: bad args");
+    P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_pack_pair_idx: too many pixels");
+    const int esz = dtype == P2P_BF16 ? 2 : 4;
+    const p2p_tensor* vs[4] = {v_src, v_c6, v_dreal, v_dfake};
+    for (int k = 0; k < 4; ++k)
+        P2P_REQUIRE(!vs[k] || (vs[k]->ptr && vs[k]->ld % 8 == 0 && ((uintptr_t)vs[k]->ptr % (8 * esz)) == 0),
+                    "p2p_pack_pair_idx: views must start on an 8-channel boundary (whole 16/32-byte pixels)");
+    TView none;
+    none.ptr = nullptr; none.img = 0; none.row = 0; none.ld = 0;
+    long long blocks = ((long long)N * H * W + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    P2P_DISPATCH_DTYPE(dtype, (pack_pair_idx_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
+                                  N, PixDec::make(H, W), source, target, make_view(v_src), v_c6 ? make_view(v_c6) : none,
+                                  make_view(v_dreal), make_view(v_dfake))));
+    return p2p_check_launch("p2p_pack_pair_idx");
+}
+
 extern "C" int p2p_pack_input_multi(int dtype, int N, int H, int W, int C, const void* src, int src_is_int,
                                     const p2p_tensor* dsts, int ndst, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && src && dsts && ndst >= 1 && ndst <= 4, "p2p_pack_input_multi: bad args");

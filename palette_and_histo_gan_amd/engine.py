@@ -1456,8 +1456,14 @@ class Pix2PixEngine:
     def _train_step_indexed_body(self, P, B, Bg, src_t, real_t, lambda_segmentation, masks, apply_update):
         S = self.S
         self._bind_batch(src_t, real_t)
-        self._pack_source(P, src_t, with_disc=True)
-        self._pack(P, real_t, P["dcat"].view(coff=0), 1, ptr=self._slot_real)
+        if self.full_pixels and self.in_ch == 1 and self.src_ch == 8 and self.dcat_ch == 8:
+            # source and target indices in one launch, whole 16-byte pixels (networks.py:45,92-94)
+            L.call("p2p_pack_pair_idx", self.dtype, B, S, S, self._slot_src, self._slot_real, C.byref(P["src"].view()),
+                   None if self._c6_tail(P) else C.byref(P["c"][6].view(coff=UP_FILTERS[5])), C.byref(P["dcat"].view(coff=0)),
+                   C.byref(P["dcat"].view(coff=0, n0=B)), _stream())
+        else:
+            self._pack_source(P, src_t, with_disc=True)
+            self._pack(P, real_t, P["dcat"].view(coff=0), 1, ptr=self._slot_real)
         self._early_side(P, masks, apply_update)
         fused = (self.use_mfma and self.use_head_fused and
                  L.lib().p2p_head_softmax_ok(self.dtype, B, S, S, self.c6_ch, self.out_ch))

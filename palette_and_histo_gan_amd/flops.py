@@ -166,6 +166,9 @@ def call_work(name, args, dtype):
         _, n, h, w = _ints(args, 4)
         ch = 8 + 8 + (0 if _null(args[7]) else 8) + (0 if _null(args[9]) else 4)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2 * 4 * 4.0 + ch * esz)}
+    if name == "p2p_pack_pair_idx":
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * (2 * 4.0 + (24 + (0 if _null(args[7]) else 8)) * esz)}
     if name == "p2p_tanh_l1_fwd_pair":          # z (4 ch) + [target | source] in, [fake | source] out (+ the f32 copy of fake)
         _, n, h, w = _ints(args, 4)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * ((4 + 8 + 8) * esz + (0.0 if _null(args[9]) else 16.0))}

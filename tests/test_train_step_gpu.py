@@ -180,6 +180,30 @@ def test_whole_pixel_stores_equal_the_partial_ones(dtype, hist):
             assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
 
 
+def test_whole_pixel_stores_of_the_indexed_batch_equal_the_partial_ones():
+    """P2P_FULL_PIXELS, indexed model: p2p_pack_pair_idx writes whole [source 0..] / [target source 0..] / [0 source 0..] pixels
+    where the generic packers stored single channels; same buffers, same weights after three steps."""
+    from palette_and_histo_gan_amd import dataset_utils as DU
+    B, S = 3, 64
+    batches = list(DU.synthetic_indexed_ds(3 * B, batch_size=B, seed=9))
+    engines, losses = [], []
+    for whole in (True, False):
+        eng = E.Pix2PixEngine(1, 256, "softmax", S, L.BF16, seed=8)
+        eng.full_pixels = whole
+        for b in batches:
+            out = eng.train_step_indexed(b[0], b[1], 0.01)
+        torch.cuda.synchronize()
+        engines.append(eng)
+        losses.append(out.cpu().numpy())
+    a, b = engines
+    assert torch.equal(a.plan(B)["c"][6].t, b.plan(B)["c"][6].t) and torch.equal(a.plan(B)["dcat"].t, b.plan(B)["dcat"].t)
+    assert torch.equal(a.plan(B)["src"].t, b.plan(B)["src"].t)
+    np.testing.assert_array_equal(losses[0], losses[1])
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        for buf in ("params", "m", "v"):
+            assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
+
+
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_adam_fused_with_the_weight_copies_equals_the_two_launch_form(dtype):
     """p2p_adam_prep_batched (Adam + operand copies in one pass) against p2p_adam_flat_dev followed by
