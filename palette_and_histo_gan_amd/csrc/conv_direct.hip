@@ -190,17 +190,33 @@ __global__ __launch_bounds__(256) void view_colsum_px8(int N, int LH, int LW, in
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int m = m0 + threadIdx.x; m < m1; m += 256) {
-        const int x = m % LW, q = m / LW, y = q % LH, n = q / LH;
-        const T* p = (const T*)lo.ptr + lo.off(n, y, x);
+    // four pixels per trip, their loads issued together (a 2048-pixel chunk is two trips: the launch is latency-bound)
+    for (int mb = m0 + threadIdx.x; mb < m1; mb += 1024) {
+        const T* p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = mb + 256 * u < m1 ? mb + 256 * u : mb;
+            const int x = m % LW, q = m / LW, y = q % LH, n = q / LH;
+            p[u] = (const T*)lo.ptr + lo.off(n, y, x);
+        }
         if (sizeof(T) == 2) {
-            const bf16x8 r = *(const bf16x8*)p;
+            bf16x8 r[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] += (float)r[k];
+            for (int u = 0; u < 4; ++u) r[u] = *(const bf16x8*)p[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (mb + 256 * u < m1)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += (float)r[u][k];
         } else {
-            const f32x4 r0 = *(const f32x4*)p, r1 = *(const f32x4*)((const float*)p + 4);
+            f32x4 r0[4], r1[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { acc[k] += r0[k]; acc[4 + k] += r1[k]; }
+            for (int u = 0; u < 4; ++u) { r0[u] = *(const f32x4*)p[u]; r1[u] = *(const f32x4*)((const float*)p[u] + 4); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (mb + 256 * u < m1)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { acc[k] += r0[u][k]; acc[4 + k] += r1[u][k]; }
         }
     }
 #pragma unroll
@@ -227,8 +243,9 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
 
 // out[d] = sum over all pixels of v[m][d]  (bias gradients of the two stride-1 heads, networks.py:47-48,75-78)
 // pixels per workgroup of the form p2p_view_colsum picks (shared with p2p_view_colsum_workspace_bytes)
+static bool view_colsum_is_px8(int C, const p2p_tensor* v) { return C <= 8 && v->ld == 8 && ((uintptr_t)v->ptr % 16) == 0; }
 static int view_colsum_chunk(int dtype, int C, const p2p_tensor* v) {
-    if (C <= 8 && v->ld == 8 && ((uintptr_t)v->ptr % 16) == 0) return 4096;     // 256 workgroups at 256 x 64 x 64
+    if (view_colsum_is_px8(C, v)) return 2048;     // 512 workgroups at 256 x 64 x 64
     const int vn = dtype == P2P_BF16 ? 8 : 4;
     if (C >= 64 && C % vn == 0 && C / vn <= 256 && 256 % (C / vn) == 0 && v->ld % vn == 0 && ((uintptr_t)v->ptr % 16) == 0) return 1024;
     return C >= 64 ? 256 : 2048;                  // wide pixels: few pixel lanes per workgroup -> more workgroups
@@ -249,7 +266,7 @@ extern "C" int p2p_view_colsum(int dtype, int N, int H, int W, int C, const p2p_
     P2P_REQUIRE(M < (1LL << 31), "p2p_view_colsum: too many pixels");
     const int chunk = view_colsum_chunk(dtype, C, v);
     const unsigned nb = (unsigned)((M + chunk - 1) / chunk);
-    if (chunk == 4096) {
+    if (view_colsum_is_px8(C, v)) {
         P2P_DISPATCH_DTYPE(dtype, (view_colsum_px8<T><<<dim3(nb), 256, 0, st>>>(N, H, W, C, make_view(v), workspace, chunk)));
     } else if (chunk == 1024) {
         P2P_DISPATCH_DTYPE(dtype, (view_colsum_vec<T><<<dim3(nb), 256, 0, st>>>(N, H, W, C, make_view(v), workspace, chunk)));
