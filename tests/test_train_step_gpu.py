@@ -276,6 +276,30 @@ def test_host_side_step_replay_is_bit_identical_to_eager_launching(kind):
     assert int(a.mask_counter_dev[0]) == int(b.mask_counter_dev[0])
 
 
+def test_whole_step_hipgraph_replay_equals_eager_launching():
+    """engine.graphed_rgba_step captures one train step (every kernel, the forks and joins between the streams through the
+    device-only events) and replays it; four steps over changing batches must leave the same weights, moments and losses as four
+    eager steps, bit for bit (Adam's step count / step size and the dropout counter live in device memory)."""
+    from palette_and_histo_gan_amd import dataset_utils as DU
+    B, S = 4, 64
+    batches = list(DU.synthetic_rgba_ds(4 * B, batch_size=B, palette_size=24, seed=11))
+    runs = []
+    for graphed in (True, False):
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, L.BF16, seed=12)
+        eng.replay_enabled = False
+        step = eng.graphed_rgba_step(B, 30.0) if graphed else (lambda s, r: eng.train_step_rgba(s, r, 30.0))
+        losses = [step(torch.as_tensor(b[0]).cuda(), torch.as_tensor(b[1]).cuda()).clone() for b in batches]
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), eng))
+    (la, a), (lb, b) = runs
+    assert torch.equal(la, lb), (la - lb).abs().max()
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        assert sa.t == sb.t == len(batches) and int(sa.t_dev[0]) == int(sb.t_dev[0]) == len(batches)
+        for buf in ("params", "m", "v"):
+            assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
+    assert int(a.mask_counter_dev[0]) == int(b.mask_counter_dev[0])
+
+
 def test_generate_is_forward_of_train_step():
     B, S = 2, 64
     rng, Gp, Dp, src, tgt, masks = setup_case(B, S, 23)
