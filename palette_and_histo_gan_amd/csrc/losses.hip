@@ -10,7 +10,7 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 // partials[k * P2P_LOSS_BLOCKS + b] = workgroup b's share of k = 0: BCE(1, real), 1: BCE(0, fake), 2: BCE(1, fake)
 // (scaled by inv_count); p2p_loss_partials_sum adds them in workgroup order
 template <typename T>
-__global__ __launch_bounds__(256) void bce_logits_kernel(int N2, int n_real, PixDec dec, TView logits, float inv_count, TView dld,
+__global__ __launch_bounds__(1024) void bce_logits_kernel(int N2, int n_real, PixDec dec, TView logits, float inv_count, TView dld,
                                                          TView dlg, float* __restrict__ partials) {
     __shared__ float red[16];
     const unsigned total = (unsigned)N2 * dec.H * dec.W;
@@ -162,7 +162,7 @@ extern "C" int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const
     TView g;
     if (dlogits_g && dlogits_g->ptr) g = make_view(dlogits_g);
     else { g.ptr = nullptr; g.img = 0; g.row = 0; g.ld = 0; }
-    P2P_DISPATCH_DTYPE(dtype, (bce_logits_kernel<T><<<dim3(P2P_LOSS_BLOCKS), 256, 0, st>>>(
+    P2P_DISPATCH_DTYPE(dtype, (bce_logits_kernel<T><<<dim3(P2P_LOSS_BLOCKS), 1024, 0, st>>>(
                                   N2, n_real, PixDec::make(H, W), make_view(logits), inv_count, make_view(dlogits_d), g, partials)));
     return p2p_check_launch("p2p_bce_logits");
 }

@@ -628,7 +628,9 @@ class Pix2PixEngine:
         P["d_draw"] = HaloBuf(2 * B, h2, h2, 64, dt, dev)
         P["d_draw_g"] = HaloBuf(B, h2, h2, 64, dt, dev)      # generator path: own buffer (D.down's wgrad may still read d_draw)
         P["g_dact_g"] = DenseBuf(B, h2, h2, 64, tdt, dev)
-        P["g_dcat"] = DenseBuf(B, S, S, self.dcat_ch, tdt, dev)
+        # d(D.first)/d(fake): only the image's channels carry a gradient; with 4 of them the buffer is dense 4-channel pixels, so the
+        # kernel that writes them stores whole pixels (in an 8-channel pixel the 8 of 16 bytes are a partial sector write)
+        P["g_dcat"] = DenseBuf(B, S, S, 4 if (self.in_ch == 4 and self.full_pixels) else self.dcat_ch, tdt, dev)
         if not self.use_mfma:
             P["d_raw"] = DenseBuf(2 * B, h2, h2, 64, tdt, dev)
         P["nws"] = torch.empty(max(B, 2) * 16 * 1024 * 2, dtype=torch.float32, device=dev)   # norm split partials [N][16][C<=1024][2]
