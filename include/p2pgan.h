@@ -248,6 +248,11 @@ int p2p_loss_partials_sum(const float* partials, int K, float* out, void* stream
 int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits,
                    float inv_count, const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g,
                    float* partials, void* stream);
+/* As p2p_bce_logits for gradient views of 8-channel pixels [g | 7 padding channels] (the operand layout of the few-channel
+ * convolution kernels): whole pixels are stored -- a 2-byte store into a 16-byte pixel is a partial sector write. */
+int p2p_bce_logits_pad8(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits,
+                        float inv_count, const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g,
+                        float* partials, void* stream);
 
 /* fake = tanh(z) written to `fake` view; partials row 0 = inv_count * sum |real - fake| over all C channels.
  * fake_f32 (may be null): dense f32 [N*H*W][C] copy of tanh(z) before rounding to `dtype` -- the histogram loss reads its
@@ -263,6 +268,10 @@ int p2p_tanh_l1_fwd_pair(int dtype, int N, int H, int W, const p2p_tensor* z, co
 int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
                     const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale,
                     const p2p_tensor* dz, void* stream);
+/* As p2p_tanh_l1_bwd (C = 4) for a dz view of 8-channel pixels [dz | 4 padding channels]: whole-pixel stores. */
+int p2p_tanh_l1_bwd_pad8(int dtype, int N, int H, int W, const p2p_tensor* fake, const p2p_tensor* real,
+                         const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale, const p2p_tensor* dz,
+                         void* stream);
 
 /* ---- RGB-uv histogram + Hellinger loss (histogram.py:4-89, pix2pix_model.py:242-250) ------------------------- */
 

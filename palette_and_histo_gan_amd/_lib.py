@@ -48,10 +48,12 @@ SIGNATURES = {
     "p2p_colsum": [_vp, _i, _i, _f, _vp, _vp],
     "p2p_colsum_batched": [_vp, _vp, _i, _i, _vp, _vp],
     "p2p_bce_logits": [_i, _i, _i, _i, _i, _TP, _f, _TP, _TP, _vp, _vp],
+    "p2p_bce_logits_pad8": [_i, _i, _i, _i, _i, _TP, _f, _TP, _TP, _vp, _vp],
     "p2p_loss_partials_sum": [_vp, _i, _vp, _vp],
     "p2p_tanh_l1_fwd": [_i, _i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp, _vp],
     "p2p_tanh_l1_fwd_pair": [_i, _i, _i, _i, _TP, _TP, _TP, _f, _vp, _vp, _vp],
     "p2p_tanh_l1_bwd": [_i, _i, _i, _i, _i, _TP, _TP, _GP, _GP, _f, _TP, _vp],
+    "p2p_tanh_l1_bwd_pad8": [_i, _i, _i, _i, _TP, _TP, _GP, _GP, _f, _TP, _vp],
     "p2p_adam_flat": [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp],
     "p2p_adam_tick": [_vp, _vp, _f, _f, _f, _vp],
     "p2p_adam_flat_dev": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp],

@@ -9,9 +9,23 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 
 // partials[k * P2P_LOSS_BLOCKS + b] = workgroup b's share of k = 0: BCE(1, real), 1: BCE(0, fake), 2: BCE(1, fake)
 // (scaled by inv_count); p2p_loss_partials_sum adds them in workgroup order
-template <typename T>
+// PAD8: the gradient views hold 8-channel pixels whose channels 1..7 are padding (the operand layout of the few-channel
+// convolution kernels): the whole pixel [g 0 0 0 0 0 0 0] is stored -- a 2-byte store into a 16-byte pixel is a partial sector
+template <typename T, bool PAD8>
 __global__ __launch_bounds__(1024) void bce_logits_kernel(int N2, int n_real, PixDec dec, TView logits, float inv_count, TView dld,
                                                          TView dlg, float* __restrict__ partials) {
+    typedef __attribute__((__vector_size__(8 * sizeof(T)))) T vec8_t;
+    auto put = [](T* p, T v) {
+        if (PAD8) {
+            vec8_t q;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = from_f32<T>(0.f);
+            q[0] = v;
+            *(vec8_t*)p = q;
+        } else {
+            *p = v;
+        }
+    };
     __shared__ float red[16];
     const unsigned total = (unsigned)N2 * dec.H * dec.W;
     float l[3] = {0.f, 0.f, 0.f};
@@ -22,12 +36,12 @@ __global__ __launch_bounds__(1024) void bce_logits_kernel(int N2, int n_real, Pi
         float s = sigmoidf(v);
         if (n < n_real) {
             l[0] += bce_logit(v, 1.f);
-            ((T*)dld.ptr)[dld.off(n, y, x)] = from_f32<T>((s - 1.f) * inv_count);
+            put((T*)dld.ptr + dld.off(n, y, x), from_f32<T>((s - 1.f) * inv_count));
         } else {
             l[1] += bce_logit(v, 0.f);
             l[2] += bce_logit(v, 1.f);
-            ((T*)dld.ptr)[dld.off(n, y, x)] = from_f32<T>(s * inv_count);
-            if (dlg.ptr) ((T*)dlg.ptr)[dlg.off(n - n_real, y, x)] = from_f32<T>((s - 1.f) * inv_count);
+            put((T*)dld.ptr + dld.off(n, y, x), from_f32<T>(s * inv_count));
+            if (dlg.ptr) put((T*)dlg.ptr + dlg.off(n - n_real, y, x), from_f32<T>((s - 1.f) * inv_count));
         }
     }
 #pragma unroll
@@ -108,10 +122,11 @@ __device__ __forceinline__ void gsrc_load4(const GSrc& g, long long pix, float* 
     }
 }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool PAD8 = false>
 __global__ void tanh_l1_bwd_kernel(int N, PixDec dec, int C, TView fake, TView real, GSrc gd, GSrc gx,
                                    float l1_scale, TView dz) {
     typedef __attribute__((__vector_size__(4 * sizeof(T)))) T vec4_t;
+    typedef __attribute__((__vector_size__(8 * sizeof(T)))) T vec8_t;
     const unsigned npix = (unsigned)N * dec.H * dec.W;
     for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
         int n, y, x;
@@ -132,7 +147,14 @@ __global__ void tanh_l1_bwd_kernel(int N, PixDec dec, int C, TView fake, TView r
                 const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
                 out[c] = from_f32<T>((g1[c] + g2[c] + l1_scale * sgn) * (1.f - f * f));
             }
-            *(vec4_t*)dp = out;
+            if (PAD8) {       // dz holds 8-channel pixels [dz | 4 padding channels]: whole-pixel store
+                vec8_t o8;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { o8[c] = out[c]; o8[4 + c] = from_f32<T>(0.f); }
+                *(vec8_t*)dp = o8;
+            } else {
+                *(vec4_t*)dp = out;
+            }
             continue;
         }
         for (int c = 0; c < C; ++c) {
@@ -153,8 +175,8 @@ extern "C" int p2p_loss_partials_sum(const float* partials, int K, float* out, v
     return p2p_check_launch("p2p_loss_partials_sum");
 }
 
-extern "C" int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits, float inv_count,
-                              const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g, float* partials, void* stream) {
+static int bce_logits_impl(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits, float inv_count,
+                           const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g, float* partials, bool pad8, void* stream) {
     P2P_REQUIRE(N2 > 0 && n_real >= 0 && n_real <= N2 && H > 0 && W > 0, "p2p_bce_logits: bad shape");
     P2P_REQUIRE(logits && logits->ptr && dlogits_d && dlogits_d->ptr && partials, "p2p_bce_logits: null pointer");
     P2P_REQUIRE((long long)N2 * H * W < (1LL << 31), "p2p_bce_logits: too many pixels");
@@ -162,9 +184,29 @@ extern "C" int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const
     TView g;
     if (dlogits_g && dlogits_g->ptr) g = make_view(dlogits_g);
     else { g.ptr = nullptr; g.img = 0; g.row = 0; g.ld = 0; }
-    P2P_DISPATCH_DTYPE(dtype, (bce_logits_kernel<T><<<dim3(P2P_LOSS_BLOCKS), 1024, 0, st>>>(
-                                  N2, n_real, PixDec::make(H, W), make_view(logits), inv_count, make_view(dlogits_d), g, partials)));
+    if (pad8) {
+        const int esz = dtype == P2P_BF16 ? 2 : 4;
+        auto ok = [&](const p2p_tensor* t) { return !t || !t->ptr || (t->ld % 8 == 0 && ((uintptr_t)t->ptr % (8 * esz)) == 0); };
+        P2P_REQUIRE(ok(dlogits_d) && ok(dlogits_g), "p2p_bce_logits_pad8: the gradient views must be whole 8-channel pixels");
+        P2P_DISPATCH_DTYPE(dtype, (bce_logits_kernel<T, true><<<dim3(P2P_LOSS_BLOCKS), 1024, 0, st>>>(
+                                      N2, n_real, PixDec::make(H, W), make_view(logits), inv_count, make_view(dlogits_d), g, partials)));
+    } else {
+        P2P_DISPATCH_DTYPE(dtype, (bce_logits_kernel<T, false><<<dim3(P2P_LOSS_BLOCKS), 1024, 0, st>>>(
+                                      N2, n_real, PixDec::make(H, W), make_view(logits), inv_count, make_view(dlogits_d), g, partials)));
+    }
     return p2p_check_launch("p2p_bce_logits");
+}
+
+extern "C" int p2p_bce_logits(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits, float inv_count,
+                              const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g, float* partials, void* stream) {
+    return bce_logits_impl(dtype, N2, n_real, H, W, logits, inv_count, dlogits_d, dlogits_g, partials, false, stream);
+}
+
+// As p2p_bce_logits for gradient views that are 8-channel pixels [g | 7 padding channels]: whole pixels are stored (the padding
+// is written as zeros, which it holds anyway).
+extern "C" int p2p_bce_logits_pad8(int dtype, int N2, int n_real, int H, int W, const p2p_tensor* logits, float inv_count,
+                                   const p2p_tensor* dlogits_d, const p2p_tensor* dlogits_g, float* partials, void* stream) {
+    return bce_logits_impl(dtype, N2, n_real, H, W, logits, inv_count, dlogits_d, dlogits_g, partials, true, stream);
 }
 
 extern "C" int p2p_tanh_l1_fwd(int dtype, int N, int H, int W, int C, const p2p_tensor* z, const p2p_tensor* real,
@@ -237,9 +279,9 @@ extern "C" int p2p_tanh_l1_fwd_pair(int dtype, int N, int H, int W, const p2p_te
     return p2p_check_launch("p2p_tanh_l1_fwd_pair");
 }
 
-extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
-                               const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale, const p2p_tensor* dz,
-                               void* stream) {
+static int tanh_l1_bwd_impl(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
+                            const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale, const p2p_tensor* dz, bool pad8,
+                            void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "p2p_tanh_l1_bwd: bad shape");
     P2P_REQUIRE(fake && fake->ptr && real && real->ptr && dz && dz->ptr, "p2p_tanh_l1_bwd: null pointer");
     P2P_REQUIRE((long long)N * H * W < (1LL << 31), "p2p_tanh_l1_bwd: too many pixels");
@@ -253,7 +295,13 @@ extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_
         return g->kind == 1 ? ((uintptr_t)g->ptr % (4 * esz)) == 0 : (((uintptr_t)g->ptr % 16) == 0 && g->slab_stride % 4 == 0);
     };
     const bool vec = C == 4 && al(fake) && al(real) && al(dz) && gal(g_d) && gal(g_extra);
-    if (vec) {
+    if (pad8) {
+        P2P_REQUIRE(vec && dz->ld % 8 == 0 && ((uintptr_t)dz->ptr % (8 * esz)) == 0,
+                    "p2p_tanh_l1_bwd_pad8: 4-channel images, dz in whole 8-channel pixels, aligned views");
+        P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T, true, true><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
+                                      N, PixDec::make(H, W), C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
+                                      l1_scale, make_view(dz))));
+    } else if (vec) {
         P2P_DISPATCH_DTYPE(dtype, (tanh_l1_bwd_kernel<T, true><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
                                       N, PixDec::make(H, W), C, make_view(fake), make_view(real), make_gsrc(g_d), make_gsrc(g_extra),
                                       l1_scale, make_view(dz))));
@@ -263,4 +311,18 @@ extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_
                                       l1_scale, make_view(dz))));
     }
     return p2p_check_launch("p2p_tanh_l1_bwd");
+}
+
+extern "C" int p2p_tanh_l1_bwd(int dtype, int N, int H, int W, int C, const p2p_tensor* fake, const p2p_tensor* real,
+                               const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale, const p2p_tensor* dz,
+                               void* stream) {
+    return tanh_l1_bwd_impl(dtype, N, H, W, C, fake, real, g_d, g_extra, l1_scale, dz, false, stream);
+}
+
+// As p2p_tanh_l1_bwd (C = 4) for a dz view of 8-channel pixels [dz | 4 padding channels] (the operand layout of the head's
+// weight- and data-gradient kernels): whole pixels are stored, the padding as the zeros it holds anyway.
+extern "C" int p2p_tanh_l1_bwd_pad8(int dtype, int N, int H, int W, const p2p_tensor* fake, const p2p_tensor* real,
+                                    const p2p_gsrc* g_d, const p2p_gsrc* g_extra, float l1_scale, const p2p_tensor* dz,
+                                    void* stream) {
+    return tanh_l1_bwd_impl(dtype, N, H, W, 4, fake, real, g_d, g_extra, l1_scale, dz, true, stream);
 }

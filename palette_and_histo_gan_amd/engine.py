@@ -1152,16 +1152,22 @@ class Pix2PixEngine:
         self.discriminator_forward(P, 2 * B)
         h2 = S // 2
         inv_bce = 1.0 / (Bg * h2 * h2)
-        L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), inv_bce,
-               C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.loss_part), _stream())
+        # (dld / dlg are 8-channel pixels [g | padding]: whole-pixel stores with the switch on)
+        L.call("p2p_bce_logits_pad8" if self.full_pixels else "p2p_bce_logits", self.dtype, 2 * B, B, h2, h2,
+               C.byref(P["logits"].view()), inv_bce, C.byref(P["dld"].view()), C.byref(P["dlg"].view()), _p(self.loss_part), _stream())
         P["skip_g_through_d"] = False
         P["head_dbias_done"] = False
         self.discriminator_backward(P, B)
         if lambda_hist is not None:
             self.side_hist.join()
-        L.call("p2p_tanh_l1_bwd", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), C.byref(real_view),
-               C.byref(P["g_dcat"].gsrc()), C.byref(g_extra) if g_extra is not None else None,
-               float(lambda_l1) * inv_l1, C.byref(P["dz"].view()), _stream())
+        if self.full_pixels and self.out_ch == 4 and self.dz_ch == 8:
+            L.call("p2p_tanh_l1_bwd_pad8", self.dtype, B, S, S, C.byref(fake_view), C.byref(real_view),
+                   C.byref(P["g_dcat"].gsrc()), C.byref(g_extra) if g_extra is not None else None,
+                   float(lambda_l1) * inv_l1, C.byref(P["dz"].view()), _stream())
+        else:
+            L.call("p2p_tanh_l1_bwd", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), C.byref(real_view),
+                   C.byref(P["g_dcat"].gsrc()), C.byref(g_extra) if g_extra is not None else None,
+                   float(lambda_l1) * inv_l1, C.byref(P["dz"].view()), _stream())
         self.generator_backward(P)
         return self._finish_step(P, lambda_l1, lambda_hist, apply_update)
 
@@ -1487,8 +1493,8 @@ class Pix2PixEngine:
                    _p(self._softmax_part()), _p(self.losses, 5), _stream())
         self.discriminator_forward(P, 2 * B)
         h2 = S // 2
-        L.call("p2p_bce_logits", self.dtype, 2 * B, B, h2, h2, C.byref(P["logits"].view()), 1.0 / (Bg * h2 * h2),
-               C.byref(P["dld"].view()), None, _p(self.loss_part), _stream())
+        L.call("p2p_bce_logits_pad8" if self.full_pixels else "p2p_bce_logits", self.dtype, 2 * B, B, h2, h2,
+               C.byref(P["logits"].view()), 1.0 / (Bg * h2 * h2), C.byref(P["dld"].view()), None, _p(self.loss_part), _stream())
         P["skip_g_through_d"] = True
         self.discriminator_backward(P, B)
         self.generator_backward(P)

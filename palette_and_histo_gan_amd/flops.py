@@ -172,6 +172,9 @@ def call_work(name, args, dtype):
     if name == "p2p_tanh_l1_fwd_pair":          # z (4 ch) + [target | source] in, [fake | source] out (+ the f32 copy of fake)
         _, n, h, w = _ints(args, 4)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * ((4 + 8 + 8) * esz + (0.0 if _null(args[9]) else 16.0))}
+    if name == "p2p_tanh_l1_bwd_pad8":
+        _, n, h, w = _ints(args, 4)
+        return {"flops": 0.0, "mfma": None, "bytes": n * h * w * 3.0 * 8 * esz}
     if name in ("p2p_tanh_l1_fwd", "p2p_tanh_l1_bwd"):
         _, n, h, w, c = _ints(args, 5)
         return {"flops": 0.0, "mfma": None, "bytes": n * h * w * 3.0 * max(c, 8) * esz}
