@@ -600,7 +600,11 @@ class Pix2PixEngine:
             if UP_DROPOUT[i - 1]:
                 P["mask"][i] = torch.empty((B * res * res, f), dtype=torch.uint8, device=dev)
         # gradient sources: d(concat_k) for k=1..6, d(a_k) from the down path
-        P["gc"] = [None] + [DenseBuf(B, P["c"][k].h, P["c"][k].w, P["c"][k].c, tdt, dev) for k in range(1, 7)]
+        # d(concat k).  The source channels of concat 6 have no gradient: its buffer holds up6's 32 channels only, so the head's data
+        # gradient stores whole 64-byte pixels (in a 40-channel pixel they straddle 32-byte sectors: partial writes and reads)
+        P["gc"] = [None] + [DenseBuf(B, P["c"][k].h, P["c"][k].w,
+                                     UP_FILTERS[5] if (k == 6 and self.full_pixels and self.use_mfma) else P["c"][k].c, tdt, dev)
+                            for k in range(1, 7)]      # (the direct cross-check kernels write every input channel)
         P["ga"] = {i: DenseBuf(B, S // 2 ** i, S // 2 ** i, DOWN_FILTERS[i - 1], tdt, dev) for i in range(1, 7)}
         # dgamma/dbeta per-image partials of every InstanceNorm layer + the task table of the one batched
         # reduction that ends the backward pass: rows = {part_off, rows, cols, out_off}
