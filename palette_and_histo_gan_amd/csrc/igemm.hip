@@ -20,6 +20,7 @@
 //              33(+7)-channel indexed concat), plus bias / LeakyReLU / column mask in the epilogue.
 #include "p2p_common.hpp"
 #include <stdlib.h>
+#include <utility>
 
 // Diagnostic builds only (tools/ubench/igemm_abl.py): 1 = staging without the LDS reads / MFMAs, 2 = LDS reads + MFMAs
 // without the staging.  The product library is always built with 0.
@@ -68,6 +69,140 @@ __device__ __forceinline__ void mfma_step(f32x16& acc, const f32x4& a, const f32
 __device__ __forceinline__ void glds16(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// Epilogue shared by both kernel forms: D[row = n][col = m]: col = lane&31 (pixel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (channel).
+// KG = 2 (igemm_pipe_kernel): after the exchange the EVEN physical fragment rows of K group `kg` hold the logical rows i + kg; a wave
+// stores those only.
+template <typename T, bool GEN, bool VEPI, int BM, int BN, int NTHR, int TM, int TN, int KG>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], char* smem, const int tid, const int lane,
+                                               const int h, const int wm, const int wn, const int kg, const int m0, const int n0,
+                                               const int ks, const int phase) {
+    const int ph = phase >> 1, pw = phase & 1;
+    auto out_pixel = [&](int m) -> long long {
+        int x = m & (a.LW - 1);
+        int y = (m >> a.lgLW) & (a.LH - 1);
+        int n = m >> (a.lgLW + a.lgLH);
+        if (a.mode == 1) return (long long)n * a.out_img + (long long)(2 * y + ph) * a.out_row + (2 * x + pw);
+        return (long long)n * a.out_img + (long long)y * a.out_row + x;
+    };
+    const bool to_slabs = a.splitk > 1;
+    if constexpr (VEPI) {
+        // stage the tile through LDS as [pixel][channel] in the OUTPUT type, then store whole 16-byte chunks of
+        // each pixel's channel run (coalesced rows instead of 2-byte scatter).
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();      // every wave is done reading the operand tiles
+        auto run = [&](auto tag) {
+            typedef decltype(tag) TO;
+            constexpr int osz = sizeof(TO);
+            constexpr int RS = BN * osz + 16;     // padded row stride (16-byte aligned rows; the 32 pixel lanes' 4-channel writes hit distinct banks)
+            typedef __attribute__((__vector_size__(4 * sizeof(TO)))) TO vec4_t;
+            constexpr int CE = 16 / osz, CPR = BN / CE, RPP = NTHR / CPR;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (KG > 1 && (i % KG) != 0) continue;          // K groups: even physical rows only, logical row = i + kg
+                int ml = (wm * TM + i + (KG > 1 ? kg : 0)) * 32 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int nl = (wn * TN + j) * 32 + 8 * g + 4 * h;
+                        vec4_t v4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float v = acc[i][j][4 * g + k];
+                            if (GEN && !to_slabs) {
+                                int col = n0 + nl + k;
+                                if (a.bias && col < a.ncols) v += a.bias[col];
+                                if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
+                            }
+                            v4[k] = from_f32<TO>(v);
+                        }
+                        *(vec4_t*)(smem + ml * RS + nl * osz) = v4;
+                    }
+                }
+            }
+            __syncthreads();
+            if (a.stat_part && !to_slabs) {
+                // InstanceNorm statistics of this tile (networks.py:18,29), taken from the ROUNDED values the consumer
+                // will read back: two passes over the LDS tile (mean, then centred squares), per group of stat_rows rows.
+                constexpr int NP = NTHR / BN;                      // row parts per column
+                float* scr = (float*)(smem + BM * RS);             // [NP][BN] scratch behind the tile
+                const int colL = tid % BN, part = tid / BN;
+                const int rows = a.stat_rows, ngrp = BM / rows;
+                for (int gI = 0; gI < ngrp; ++gI) {
+                    const int rbeg = gI * rows;
+                    float sacc = 0.f;
+                    for (int r = rbeg + part; r < rbeg + rows; r += NP) sacc += to_f32(*(const TO*)(smem + r * RS + colL * osz));
+                    scr[part * BN + colL] = sacc;
+                    __syncthreads();
+                    float mean = 0.f;
+#pragma unroll
+                    for (int q2 = 0; q2 < NP; ++q2) mean += scr[q2 * BN + colL];
+                    mean /= (float)rows;
+                    __syncthreads();
+                    float qacc = 0.f;
+                    for (int r = rbeg + part; r < rbeg + rows; r += NP) {
+                        float d = to_f32(*(const TO*)(smem + r * RS + colL * osz)) - mean;
+                        qacc += d * d;
+                    }
+                    scr[part * BN + colL] = qacc;
+                    __syncthreads();
+                    if (part == 0 && n0 + colL < a.ncols) {
+                        float m2 = 0.f;
+#pragma unroll
+                        for (int q2 = 0; q2 < NP; ++q2) m2 += scr[q2 * BN + colL];
+                        const int mrow = m0 + rbeg;
+                        const int img = mrow >> a.lgHW;
+                        const int tile_in_img = (mrow & ((1 << a.lgHW) - 1)) / rows;
+                        const int slot = phase * (a.stat_slots / (a.mode == 1 ? 4 : 1)) + tile_in_img;
+                        float* dst = a.stat_part + (((long long)img * a.stat_slots + slot) * a.ncols + n0 + colL) * 2;
+                        dst[0] = mean;
+                        dst[1] = m2;
+                    }
+                    __syncthreads();
+                }
+            }
+            TO* obase = to_slabs ? (TO*)(a.slabs + (long long)ks * a.slab_stride) : (TO*)a.out;
+            const int chunk = tid % CPR, r0 = tid / CPR;
+            const int col = n0 + chunk * CE;
+#pragma unroll
+            for (int ps = 0; ps < BM / RPP; ++ps) {
+                int ml = ps * RPP + r0;
+                int m = m0 + ml;
+                if (m < a.M && col < a.ncols) {
+                    f32x4 v = *(const f32x4*)(smem + ml * RS + chunk * 16);
+                    *(f32x4*)(obase + out_pixel(m) * a.out_ld + col) = v;
+                }
+            }
+        };
+        if (to_slabs) run(float()); else run(T());
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (KG > 1 && (i % KG) != 0) continue;
+            int m = m0 + (wm * TM + i + (KG > 1 ? kg : 0)) * 32 + (lane & 31);
+            if (m >= a.M) continue;
+            long long pix = out_pixel(m);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int col = n0 + (wn * TN + j) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (col >= a.ncols) continue;
+                    float v = acc[i][j][e];
+                    if (!to_slabs) {
+                        if (GEN) {
+                            if (a.bias) v += a.bias[col];
+                            if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
+                        }
+                        ((T*)a.out)[pix * a.out_ld + col] = from_f32<T>(v);
+                    } else {
+                        a.slabs[(long long)ks * a.slab_stride + pix * a.out_ld + col] = v;
+                    }
+                }
+        }
+    }
 }
 
 template <typename T, int WM, int WN, int TM, int TN, bool GEN, bool VEPI, int NST>
@@ -246,129 +381,293 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmArgs a) {
         }
     }
 
-    // ---- epilogue: D[row = n][col = m]: col = lane&31 (pixel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (channel) ----
-    auto out_pixel = [&](int m) -> long long {
-        int x = m & (a.LW - 1);
-        int y = (m >> a.lgLW) & (a.LH - 1);
-        int n = m >> (a.lgLW + a.lgLH);
-        if (a.mode == 1) return (long long)n * a.out_img + (long long)(2 * y + ph) * a.out_row + (2 * x + pw);
-        return (long long)n * a.out_img + (long long)y * a.out_row + x;
+    igemm_epilogue<T, GEN, VEPI, BM, BN, NTHR, TM, TN, 1>(a, acc, smem, tid, lane, h, wm, wn, 0, m0, n0, ks, phase);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form (round 4) for the encoder / decoder blocks whose K-blocks lie inside one tap (channels-per-tap bytes
+// >= 128) and whose output channels fill 128-wide tiles: the deep layers (maps <= 4x4) in bf16, every main layer in f32.
+// What the form above left on the table (ISA of r03: three ds_read_b128, s_waitcnt lgkmcnt(0), two MFMAs, four times per K-block,
+// so every 64 matrix cycles paid one full LDS round trip, and a 32x64 wave tile reads 1.5 KB of LDS per MFMA -- with the LDS-DMA
+// writes exactly the LDS array's capacity at the matrix peak):
+//   * wave tile 64x64 (TM = TN = 2): 1 KB of LDS reads per MFMA;
+//   * four fragment sets, one per 16-deep k-step of a K-block, loaded with ds_read_b128 in inline asm and retired by COUNTED
+//     s_waitcnt lgkmcnt(TM + TN): the reads of step s+1 are in flight under the MFMAs of step s;
+//   * the MFMAs of a K-block's last two k-steps are deferred across the block's single barrier, behind the first reads of the
+//     next block: the matrix pipe has 2 x TM x TN instructions of work while the barrier, the LDS latency and the LDS-DMA issue
+//     of the next stage (one piece between two MFMAs) pass;
+//   * KG = 2: two K groups of four waves inside one workgroup (8 waves, 2 per SIMD) take alternate K-blocks of the SAME 128x128
+//     output tile and exchange half of their accumulators through LDS at the end (fixed order: deterministic).  The deep layers
+//     have exactly one 128x128 tile per CU at batch 256, so the second wave of every SIMD comes from splitting K inside the
+//     workgroup instead of from f32 slabs in HBM.
+template <int... I, typename F>
+__device__ __forceinline__ void igemm_static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+__device__ __forceinline__ unsigned lds_addr32(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <typename F> __device__ __forceinline__ void lds_read16(F& d, unsigned addr) {
+    static_assert(sizeof(F) == 16, "one ds_read_b128");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr));
+}
+template <int N> __device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);      // register-only MFMAs must not be hoisted above the wait (cdna_hip_programming.md rule 18)
+}
+
+template <typename T, int MODE, int WM, int WN, int TM, int TN, int KG, int NST, bool VEPI>
+__global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs a) {
+    constexpr int NWG = WM * WN, NW = KG * NWG, NTHR = NW * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;      // one K-block (128 bytes per row) per stage
+    constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW), NL = NA + NB;                 // LDS-DMA pieces per wave per stage
+    constexpr int NF = TM + TN, NMF = TM * TN;
+    constexpr int KS = 4 / KG;                                                          // 16-deep k-steps of a K-block per wave
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave stages the same number of pieces (counted vmcnt)");
+    static_assert(KG == 1 || (KG == 2 && TM % 2 == 0), "accumulator rows are split between two K groups");
+    static_assert(NST >= 2 && NST <= 4, "ring of 2..4 stages");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave / NWG, wv = wave % NWG;
+    const int wm = wv / WN, wn = wv % WN;
+    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    int bx, by, bz;
+    if (a.w_major) { bx = lin % gridDim.x; by = (lin / gridDim.x) % gridDim.y; bz = lin / (gridDim.x * gridDim.y); }
+    else { by = lin % gridDim.y; bz = (lin / gridDim.y) % gridDim.z; bx = lin / (gridDim.y * gridDim.z); }
+    const int m0 = bx * BM, n0 = by * BN;
+    const int ks = bz % a.splitk, phase = bz / a.splitk;
+    const int ph = phase >> 1, pw = phase & 1;
+    const int tap_begin = ks * a.taps_per;
+    const int CBbytes = 1 << a.lgCB;                               // bytes per tap row (>= 128: a K-block lies inside one tap)
+    const int nkb = (a.taps_per * CBbytes) >> 7;                  // K-blocks of 128 bytes = stages
+    constexpr int esz = sizeof(T);
+    const int pixB = a.in_ld * esz, rowB = a.in_row * pixB;
+
+    // ---- staging: per-lane source addresses (row base + swizzled 16-byte slot); a K-block adds a wave-uniform offset --------------
+    const char* abq[NA];
+    int bbq[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3);
+        const int m = min(m0 + r, a.M - 1);
+        const int x = m & (a.LW - 1), y = (m >> a.lgLW) & (a.LH - 1), n = m >> (a.lgLW + a.lgLH);
+        const int byy = MODE == 0 ? a.si * y - 1 : y, bxx = MODE == 0 ? a.si * x - 1 : x;
+        abq[i] = a.in + ((long long)n * a.in_img + (long long)byy * a.in_row + bxx) * pixB + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int r = (j * NW + wave) * 8 + (lane >> 3);
+        bbq[j] = (n0 + r) * a.C * esz + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+    const int wtap = a.w_rows * a.C * esz;
+    int s_aoff;                         // wave-uniform (scalar registers): offsets of the K-block being requested
+    const char* s_wk;
+    auto stage_prepare = [&](int kb) {
+        const int kbyte0 = kb << 7;
+        int tl = tap_begin + (kbyte0 >> a.lgCB);
+        const int cb0 = kbyte0 & (CBbytes - 1);
+        int dy, dx, widx;
+        if (a.live_taps) tl = MODE == 0 ? ((1 + (tl >> 1)) << 2) + 1 + (tl & 1) : 2 * ph + pw;
+        if (MODE == 0) { dy = tl >> 2; dx = tl & 3; widx = tl; }
+        else {
+            const int kh = (1 - ph) + 2 * (tl >> 1), kw = (1 - pw) + 2 * (tl & 1);
+            dy = (ph + 1 - kh) >> 1; dx = (pw + 1 - kw) >> 1; widx = kh * 4 + kw;
+        }
+        s_aoff = dy * rowB + dx * pixB + cb0;
+        s_wk = a.w + ((long long)widx * wtap + cb0);
     };
-    const bool to_slabs = a.splitk > 1;
-    if constexpr (VEPI) {
-        // stage the tile through LDS as [pixel][channel] in the OUTPUT type, then store whole 16-byte chunks of
-        // each pixel's channel run (coalesced rows instead of 2-byte scatter).
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();      // every wave is done reading the operand tiles
-        auto run = [&](auto tag) {
-            typedef decltype(tag) TO;
-            constexpr int osz = sizeof(TO);
-            constexpr int RS = BN * osz + 16;     // padded row stride (16-byte aligned rows; the 32 pixel lanes' 4-channel writes hit distinct banks)
-            typedef __attribute__((__vector_size__(4 * sizeof(TO)))) TO vec4_t;
-            constexpr int CE = 16 / osz, CPR = BN / CE, RPP = NTHR / CPR;
+    auto stage_piece = [&](char* buf, auto pc) {          // piece p (0 .. NL-1) of this wave
+        constexpr int p = decltype(pc)::value;
+        if (P2P_ABL == 2) return;
+        if constexpr (p < NA) glds16(abq[p] + s_aoff, buf + (p * NW + wave) * 1024);
+        else glds16(s_wk + bbq[p - NA], buf + A_BYTES + ((p - NA) * NW + wave) * 1024);
+    };
+    auto stage_all = [&](int kb, char* buf) {
+        stage_prepare(kb);
+        igemm_static_for(std::make_integer_sequence<int, NL>{}, [&](auto pc) { stage_piece(buf, pc); });
+    };
+    // all but the `n` youngest stages of LDS-DMA have landed (n wave-uniform, 0 .. NST - 2)
+    auto vm_wait_stages = [&](int n) {
+        if (NST >= 4 && n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+        else if (NST >= 3 && n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int ml = (wm * TM + i) * 32 + (lane & 31);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        int nl = (wn * TN + j) * 32 + 8 * g + 4 * h;
-                        vec4_t v4;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment read addresses inside a stage: row * 128 + ((2s + h) ^ swizzle(row)) * 16 = (row * 128 + ((h ^ swizzle) << 4)) ^ (s << 5);
+    // K group kg takes the k-steps s = KS * kg .. KS * kg + KS - 1 of every K-block
+    typedef typename Frag<T>::type frag_t;
+    const int h = lane >> 5;
+    unsigned afo[KS][TM], bfo[KS][TN];
+    const unsigned sm0 = lds_addr32(smem);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float v = acc[i][j][4 * g + k];
-                            if (GEN && !to_slabs) {
-                                int col = n0 + nl + k;
-                                if (a.bias && col < a.ncols) v += a.bias[col];
-                                if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
-                            }
-                            v4[k] = from_f32<TO>(v);
-                        }
-                        *(vec4_t*)(smem + ml * RS + nl * osz) = v4;
-                    }
-                }
-            }
-            __syncthreads();
-            if (a.stat_part && !to_slabs) {
-                // InstanceNorm statistics of this tile (networks.py:18,29), taken from the ROUNDED values the consumer
-                // will read back: two passes over the LDS tile (mean, then centred squares), per group of stat_rows rows.
-                constexpr int NP = NTHR / BN;                      // row parts per column
-                float* scr = (float*)(smem + BM * RS);             // [NP][BN] scratch behind the tile
-                const int colL = tid % BN, part = tid / BN;
-                const int rows = a.stat_rows, ngrp = BM / rows;
-                for (int gI = 0; gI < ngrp; ++gI) {
-                    const int rbeg = gI * rows;
-                    float sacc = 0.f;
-                    for (int r = rbeg + part; r < rbeg + rows; r += NP) sacc += to_f32(*(const TO*)(smem + r * RS + colL * osz));
-                    scr[part * BN + colL] = sacc;
-                    __syncthreads();
-                    float mean = 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + (lane & 31);
+        const unsigned b = sm0 + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
 #pragma unroll
-                    for (int q2 = 0; q2 < NP; ++q2) mean += scr[q2 * BN + colL];
-                    mean /= (float)rows;
-                    __syncthreads();
-                    float qacc = 0.f;
-                    for (int r = rbeg + part; r < rbeg + rows; r += NP) {
-                        float d = to_f32(*(const TO*)(smem + r * RS + colL * osz)) - mean;
-                        qacc += d * d;
-                    }
-                    scr[part * BN + colL] = qacc;
-                    __syncthreads();
-                    if (part == 0 && n0 + colL < a.ncols) {
-                        float m2 = 0.f;
+        for (int s4 = 0; s4 < KS; ++s4) afo[s4][i] = b ^ ((KS * kg + s4) << 5);
+    }
 #pragma unroll
-                        for (int q2 = 0; q2 < NP; ++q2) m2 += scr[q2 * BN + colL];
-                        const int mrow = m0 + rbeg;
-                        const int img = mrow >> a.lgHW;
-                        const int tile_in_img = (mrow & ((1 << a.lgHW) - 1)) / rows;
-                        const int slot = phase * (a.stat_slots / (a.mode == 1 ? 4 : 1)) + tile_in_img;
-                        float* dst = a.stat_part + (((long long)img * a.stat_slots + slot) * a.ncols + n0 + colL) * 2;
-                        dst[0] = mean;
-                        dst[1] = m2;
-                    }
-                    __syncthreads();
-                }
-            }
-            TO* obase = to_slabs ? (TO*)(a.slabs + (long long)ks * a.slab_stride) : (TO*)a.out;
-            const int chunk = tid % CPR, r0 = tid / CPR;
-            const int col = n0 + chunk * CE;
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + (lane & 31);
+        const unsigned b = sm0 + A_BYTES + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
 #pragma unroll
-            for (int ps = 0; ps < BM / RPP; ++ps) {
-                int ml = ps * RPP + r0;
-                int m = m0 + ml;
-                if (m < a.M && col < a.ncols) {
-                    f32x4 v = *(const f32x4*)(smem + ml * RS + chunk * 16);
-                    *(f32x4*)(obase + out_pixel(m) * a.out_ld + col) = v;
-                }
-            }
-        };
-        if (to_slabs) run(float()); else run(T());
+        for (int s4 = 0; s4 < KS; ++s4) bfo[s4][j] = b ^ ((KS * kg + s4) << 5);
+    }
+    frag_t fa[4][TM], fb[4][TN];          // KG = 1: one set per k-step; KG = 2: sets {0, 1} and {2, 3} alternate between K-blocks
+    auto load_set = [&](auto sc, auto kc, unsigned bufoff) {       // set sc <- k-step kc (of this group's KS) of the stage at bufoff
+        constexpr int s4 = decltype(sc)::value, k4 = decltype(kc)::value;
+        if (P2P_ABL == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lds_read16(fa[s4][i], afo[k4][i] + bufoff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) lds_read16(fb[s4][j], bfo[k4][j] + bufoff);
+    };
+    auto mfma_set = [&](auto sc) {
+        constexpr int s4 = decltype(sc)::value;
+        if (P2P_ABL == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mfma_step(acc[i][j], fb[s4][j], fa[s4][i]);
+    };
+    // MFMAs of the sets S0 .. S0 + NS - 1 with one LDS-DMA piece of the stage being requested behind each of the first NL of
+    // them.  The MFMAs are unconditional (one code path: accumulators that live across a branch with MFMAs in both arms were
+    // copied register by register at the join); only the tiny LDS-DMA issues sit under the wave-uniform `more`.
+    auto mfma_dma = [&](auto s0c, auto nsc, const bool more, char* buf) {
+        constexpr int S0 = decltype(s0c)::value, NS = decltype(nsc)::value;
+        igemm_static_for(std::make_integer_sequence<int, NS * NMF>{}, [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int s4 = S0 + m / NMF, i = (m % NMF) / TN, j = m % TN;
+            if (P2P_ABL != 1) mfma_step(acc[i][j], fb[s4][j], fa[s4][i]);
+            if constexpr (m < NL) { if (more) stage_piece(buf, mc); }
+        });
+        if constexpr (NL > NS * NMF) {
+            if (more)
+                igemm_static_for(std::make_integer_sequence<int, (NL > NS * NMF ? NL - NS * NMF : 0)>{},
+                                 [&](auto mc) { stage_piece(buf, std::integral_constant<int, decltype(mc)::value + NS * NMF>{}); });
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ---- prologue: stages 0 .. NST-2 requested, stage 0 landed (barrier), stage NST-1 requested, first fragment sets requested -------
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nkb) stage_all(st, smem + st * STAGE);
+    vm_wait_stages(min(NST - 2, nkb - 1));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (NST - 1 < nkb) stage_all(NST - 1, smem + (NST - 1) * STAGE);
+    if constexpr (KG == 1) {
+        // four sets, one per k-step; the MFMAs of k-steps 2 and 3 run behind the barrier that ends the K-block
+        load_set(I0{}, I0{}, 0);
+        for (int it = 0; it < nkb; ++it) {
+            const unsigned cur = (unsigned)((it % NST) * STAGE);
+            char* const nbuf = smem + cur;                              // the buffer this iteration releases takes stage it + NST
+            __builtin_amdgcn_sched_barrier(0);
+            load_set(I1{}, I1{}, cur); lgkm_wait<NF>(); mfma_set(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_set(I2{}, I2{}, cur); lgkm_wait<NF>(); mfma_set(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_set(I3{}, I3{}, cur);
+            const bool more = it + NST < nkb;                           // wave-uniform
+            if (more) stage_prepare(it + NST);                          // scalar work under the waits below
+            // stage it + 1 must have landed before anybody reads it; the younger stages may stay in flight
+            vm_wait_stages(min(NST - 2, nkb - 2 - it));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // sets 2 and 3 are in registers: this stage's buffer may be overwritten
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < nkb) load_set(I0{}, I0{}, (unsigned)(((it + 1) % NST) * STAGE));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_dma(I2{}, I2{}, more, nbuf);
+        }
     } else {
+        // two K groups share every K-block (group kg: k-steps 2 kg, 2 kg + 1): stages stay 32 KB, so a ring of four leaves three
+        // K-blocks (96 KB per CU) in flight -- the launch is fed from HBM / the Infinity Cache, whose latency one 64 KB stage in
+        // flight did not cover (r04: 43 us with warm caches but 60 us inside the step, against 52 / 57 us for the r03 kernel).
+        // Per K-block and wave: MFMAs of k-step 0 | barrier | reads of the next block's two sets | MFMAs of k-step 1 + LDS-DMA.
+        auto body = [&](auto pc, int it) {
+            constexpr int P = decltype(pc)::value;
+            using X0 = std::integral_constant<int, 2 * P>; using X1 = std::integral_constant<int, 2 * P + 1>;
+            using Y0 = std::integral_constant<int, 2 - 2 * P>; using Y1 = std::integral_constant<int, 3 - 2 * P>;
+            char* const nbuf = smem + (it % NST) * STAGE;
+            const bool more = it + NST < nkb;
+            __builtin_amdgcn_sched_barrier(0);
+            lgkm_wait<NF>();                                            // X0 has landed (X1 behind it)
+            mfma_set(X0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) stage_prepare(it + NST);
+            vm_wait_stages(min(NST - 2, nkb - 2 - it));                 // stage it + 1 has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // X1 too: nobody reads stage it any more
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < nkb) {
+                const unsigned nxt = (unsigned)(((it + 1) % NST) * STAGE);
+                load_set(Y0{}, I0{}, nxt);
+                load_set(Y1{}, I1{}, nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_dma(X1{}, I1{}, more, nbuf);
+        };
+        load_set(I0{}, I0{}, 0);
+        load_set(I1{}, I1{}, 0);
+        for (int it = 0; it < nkb; it += 2) {
+            body(I0{}, it);
+            if (it + 1 < nkb) body(I1{}, it + 1);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- K groups: group g keeps fragment rows i with i % KG == g and receives the other group's partial sums for them --------------
+    if constexpr (KG == 2) {
+        // (behind the loop's last barrier nobody reads a stage buffer any more and no LDS-DMA is outstanding.)  Group 1 first
+        // swaps its fragment rows pairwise, so that every wave SENDS the odd physical rows and KEEPS the even ones with static
+        // register indices (a runtime row choice put the accumulators into scratch): physical row 2r of group g is logical row 2r + g.
+        constexpr int TMO = TM / 2;
+        if (kg) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            int m = m0 + (wm * TM + i) * 32 + (lane & 31);
-            if (m >= a.M) continue;
-            long long pix = out_pixel(m);
+            for (int r = 0; r < TMO; ++r)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { const f32x16 t = acc[2 * r][j]; acc[2 * r][j] = acc[2 * r + 1][j]; acc[2 * r + 1][j] = t; }
+        }
+#pragma unroll
+        for (int r = 0; r < TMO; ++r) {
+            const int slot = (((1 - kg) * NWG + wv) * TMO + r) * TN;           // the other group's wave with the same (wm, wn)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    int col = n0 + (wn * TN + j) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (col >= a.ncols) continue;
-                    float v = acc[i][j][e];
-                    if (!to_slabs) {
-                        if (GEN) {
-                            if (a.bias) v += a.bias[col];
-                            if (a.act == P2P_ACT_LEAKY) v = v > 0.f ? v : a.alpha * v;
-                        }
-                        ((T*)a.out)[pix * a.out_ld + col] = from_f32<T>(v);
-                    } else {
-                        a.slabs[(long long)ks * a.slab_stride + pix * a.out_ld + col] = v;
-                    }
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v = {acc[2 * r + 1][j][4 * q4], acc[2 * r + 1][j][4 * q4 + 1], acc[2 * r + 1][j][4 * q4 + 2], acc[2 * r + 1][j][4 * q4 + 3]};
+                    *(f32x4*)(smem + (slot + j) * 4096 + q4 * 1024 + lane * 16) = v;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < TMO; ++r) {
+            const int slot = ((kg * NWG + wv) * TMO + r) * TN;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 v = *(const f32x4*)(smem + (slot + j) * 4096 + q4 * 1024 + lane * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[2 * r][j][4 * q4 + k] += v[k];
                 }
         }
     }
+    igemm_epilogue<T, false, VEPI, BM, BN, NTHR, TM, TN, KG>(a, acc, smem, tid, lane, h, wm, wn, kg, m0, n0, ks, phase);
 }
 
 static int ilog2_exact(long long v) {
@@ -433,11 +732,56 @@ static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
     }
 }
 
+// Software-pipelined form: 0 = off (the r03 kernel for every shape), 1 = automatic choice, 2 = always two K groups per 128x128
+// tile, 3 = always four-wave 128x128 workgroups (two per CU), 4 = the 256x128 tile wherever its workgroups fill the chip
+static int igemm_pipe_mode() { static int v = -1; if (v < 0) v = igemm_env("P2P_IGEMM_PIPE", 1); return v; }
+
+template <typename T, int MODE, int WM, int WN, int TM, int TN, int KG, int NST>
+static void igemm_pipe_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = KG * WM * WN * 64;
+    const int ctiles = (a.ncols + 31) / 32 * 32;
+    dim3 grid((a.M + BM - 1) / BM, (ctiles + BN - 1) / BN, gz);
+    size_t shm = (size_t)NST * (BM + BN) * 128;
+    const size_t epi = (size_t)BM * (BN * 4 + 16) + 4096;      // f32 staging of the epilogue is the larger case (+ stats scratch)
+    if (vepi && epi > shm) shm = epi;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, MODE, WM, WN, TM, TN, KG, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, MODE, WM, WN, TM, TN, KG, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (vepi) igemm_pipe_kernel<T, MODE, WM, WN, TM, TN, KG, NST, true><<<grid, dim3(NTHR), shm, st>>>(a);
+    else igemm_pipe_kernel<T, MODE, WM, WN, TM, TN, KG, NST, false><<<grid, dim3(NTHR), shm, st>>>(a);
+}
+
+// The pipelined kernel takes the launch when K-blocks lie inside one tap, the columns fill 128-wide tiles and the op is a
+// stride-2 G or P; returns false otherwise (the caller falls back to igemm_kernel).
+template <typename T, int MODE>
+static bool igemm_pipe_try(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
+    const int ctiles = (a.ncols + 31) / 32 * 32;
+    const int nkb = (a.taps_per * a.C * (int)sizeof(T)) >> 7;
+    const int bm = igemm_bm(a.M, ctiles, gz);
+    const int pm = igemm_pipe_mode();
+    if (bm == 256) { igemm_pipe_go<T, MODE, 4, 2, 2, 2, 1, 3>(a, gz, vepi, st); return true; }
+    const long long tiles = ((a.M + 127) / 128) * (long long)(ctiles / 128) * gz;
+    (void)nkb;
+    const bool kg2 = pm == 2 || (pm != 3 && tiles <= 384);      // one workgroup per CU anyway: the second wave of a SIMD splits K
+    if (kg2) igemm_pipe_go<T, MODE, 2, 2, 2, 2, 2, 4>(a, gz, vepi, st);
+    else igemm_pipe_go<T, MODE, 2, 2, 2, 2, 1, 2>(a, gz, vepi, st);
+    return true;
+}
+
 template <typename T, bool GEN>
 static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
     unsigned gz = (unsigned)(phases * a.splitk);
     const int ctiles = (a.ncols + 31) / 32 * 32;      // launched columns (<= w_rows)
     const bool bigM = a.M >= 256 * 512;                // enough rows to fill the chip with 256-row tiles
+    if constexpr (!GEN) {
+        if (igemm_pipe_mode() && a.lgCB >= 7 && ctiles % 128 == 0 && a.mode <= 1) {
+            const bool ok = a.mode == 0 ? igemm_pipe_try<T, 0>(a, gz, vepi, st) : igemm_pipe_try<T, 1>(a, gz, vepi, st);
+            if (ok) return p2p_check_launch("p2p_igemm");
+        }
+    }
     if (igemm_bm(a.M, ctiles, gz) == 256 && ctiles % 128 == 0) igemm_go<T, 4, 2, 2, 2, GEN>(a, gz, vepi, st);
     // 128x128: eight waves (32x64 each), i.e. twice the waves per SIMD for the same LDS: +12 % over four 64x64 waves
     // (r01, A/B on one device); the 64- and 32-column tiles measured no better with eight waves and keep four
