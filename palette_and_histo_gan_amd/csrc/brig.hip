@@ -64,6 +64,18 @@ __device__ __forceinline__ void brig_glds16(const char* g, char* l) {
 }
 
 template <int N> __device__ __forceinline__ void brig_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Fragment reads in inline asm, retired by COUNTED waits (round 4).  With plain loads hipcc waited lgkmcnt(0) in front of every
+// second MFMA group -- i.e. for the reads it had just issued for the NEXT sub-step (the late-DMA branch between the two groups
+// splits the basic block and its wait-count bookkeeping gives up at the join): a full LDS round trip exposed per 16 MFMAs.
+__device__ __forceinline__ unsigned brig_lds32(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ void brig_read16(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); }
+template <int OFF> __device__ __forceinline__ void brig_read16_off(bf16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void brig_wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);      // the register-only MFMAs stay behind the wait
+}
 
 template <int... I, typename F>
 __device__ __forceinline__ void brig_static_for(std::integer_sequence<int, I...>, F&& f) {
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         const int tsel = row / (4 * CW), qd = (row / CW) & 3, n = row & (CW - 1);
         const long long wrow = MODE == 1 ? (long long)n0c + n : (long long)n0c + qd * CW + n;
         wbase[j] = (unsigned)(wrow * a.C * esz + q * 16 + (long long)tsel * 2 * tapB);     // second tap of a step: kw + 2
-        wq[j] = qd;
+        wq[j] = ((p << 4) / CW) & 3;       // = qd for every row of the piece (16 rows inside one CW block): wave-uniform
     }
     // tap slab of (phase | plane) pq for tap index tt = 2a + b: kh = 1 - p + 2a, kw = 1 - q + 2b
     auto widx = [](int pq, int tt) { return ((1 - (pq >> 1)) + 2 * (tt >> 1)) * 4 + (1 - (pq & 1)) + 2 * (tt & 1); };
@@ -188,14 +200,14 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
             const long long coff = (long long)kc * CK * esz;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const long long off = (long long)widx(wq[j], tt0) * tapB + coff;      // the row's phase picks the slab
-                brig_glds16(a.w + off + wbase[j], dst + (wave + 8 * j) * 1024);
+                const long long off = (long long)widx(wq[j], tt0) * tapB + coff;      // the piece's phase picks the slab (wave-uniform)
+                p2p_glds16_sv(a.w + off, wbase[j], p2p_lds32(dst) + (wave + 8 * j) * 1024);
             }
         } else {
             const int plane = kc & 3, cc = kc >> 2;
-            const char* src = a.w + (long long)widx(plane, tt0) * tapB + (long long)cc * CK * esz;
-            brig_glds16(src + wbase[0], dst + wave * 1024);
-            brig_glds16(src + wbase[1], dst + (wave + 8) * 1024);
+            const char* src = a.w + (long long)widx(plane, tt0) * tapB + (long long)cc * CK * esz;      // wave-uniform
+            p2p_glds16_sv(src, wbase[0], p2p_lds32(dst) + wave * 1024);
+            p2p_glds16_sv(src, wbase[1], p2p_lds32(dst) + (wave + 8) * 1024);
         }
     };
     auto issue_a = [&](int kc, int i) {     // piece i of this wave for K chunk kc
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         long long off;
         if (MODE == 1) off = (long long)kc * CK * esz;
         else { const int plane = kc & 3, cc = kc >> 2; off = (long long)cc * CK * esz - (plane >> 1) * rowB - (plane & 1) * pixB; }
-        brig_glds16(a.in + a.in_lo + off + abase[i], Abuf + (kc & 1) * a.abytes + adst[i]);
+        p2p_glds16_sv(a.in + a.in_lo + off, abase[i], p2p_lds32(Abuf) + (kc & 1) * a.abytes + adst[i]);
     };
 
     // ---- fragment addresses ----------------------------------------------------------------------------------------------------
@@ -216,17 +228,15 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
         aidx[pbi] = img * a.BP + ly * a.PITCH + lx;
     }
     // weight fragment offsets inside a stage: row = (tap in step * 4 + quarter) * CW + cb * 32 + r, chunk q swizzled by the row
-    int woff[TPS][2][CBW];
+    int woff[TPS][2];      // channel block cb of the wave lies 32 rows = 2048 bytes further on (same swizzle): an immediate offset
 #pragma unroll
     for (int tp = 0; tp < TPS; ++tp)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) {
-                const int row = (tp * 4 + quarter) * CW + cb * 32 + r;
-                const int q = 2 * ks + h;
-                woff[tp][ks][cb] = row * RB + ((q ^ ((row >> 2) & 3)) << 4);
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = (tp * 4 + quarter) * CW + r;
+            const int q = 2 * ks + h;
+            woff[tp][ks] = row * RB + ((q ^ ((row >> 2) & 3)) << 4);
+        }
 
     f32x16 acc[4][CBW];
 #pragma unroll
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
     };
 
     for (int kc = 0; kc < a.nkc; ++kc) {
-        const char* Acur = Abuf + (kc & 1) * a.abytes;
+        const unsigned Acur32 = brig_lds32(Abuf) + (kc & 1) * a.abytes;
         // op P: the phase of this wave; op G: the parity plane of this chunk
         const int pq = MODE == 1 ? quarter : (kc & 3);
         brig_static_for(std::make_integer_sequence<int, NT>{}, [&](auto tt) {
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
                     issue_w(kc * NT + t + NWST - 1);
                 }
             };
-            const char* Wcur = Wring + ((kc * NT + t) % NWST) * WST;
+            const unsigned Wcur32 = brig_lds32(Wring) + ((kc * NT + t) % NWST) * WST;
             auto load_set = [&](int sub, bf16x8 (&wf)[CBW], bf16x8 (&af)[4]) {
                 const int tp = sub >> 1, ks = sub & 1;
                 // tap (a, b) of the phase / plane reads block pixel (ly + da, lx + db): op P da = 1 + dy with dy = 0 / -1 (ph = 0),
@@ -297,14 +307,19 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
                 else { da = ta; db = tb; }
                 const int toff = da * a.PITCH + db;
                 const int q = 2 * ks + h;
-#pragma unroll
-                for (int cb = 0; cb < CBW; ++cb) wf[cb] = *(const bf16x8*)(Wcur + woff[tp][ks][cb]);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const unsigned wa = Wcur32 + woff[tp][ks];
+                    brig_read16(wf[0], wa);
+                    if constexpr (CBW == 2) brig_read16_off<32 * RB>(wf[CBW - 1], wa);
+                }
 #pragma unroll
                 for (int pbi = 0; pbi < 4; ++pbi) {
                     const int idx = aidx[pbi] + toff;
-                    af[pbi] = *(const bf16x8*)(Acur + idx * RB + ((q ^ ((idx >> 2) & 3)) << 4));
+                    brig_read16(af[pbi], Acur32 + idx * RB + ((q ^ ((idx >> 2) & 3)) << 4));
                 }
             };
+            constexpr int NR = CBW + 4;      // reads per fragment set
             // The two waves of a SIMD (w and w + 4) would otherwise run the same program in lockstep behind the barrier: both
             // issue their LDS-DMA (tens of cycles of issue time per instruction) while the matrix pipe idles.  The second half
             // issues its DMA after its first MFMA group instead, so one partner multiplies while the other stages.
@@ -312,19 +327,27 @@ __global__ __launch_bounds__(512) void brig_kernel(BrigArgs a) {
             if (!late || P2P_ABL == 1 || P2P_ABL == 4 || P2P_ABL == 5) issue_dma();
             if (P2P_ABL != 1 && P2P_ABL != 4 && P2P_ABL != 5) {
                 load_set(0, wfA, afA);
-                mfma_set(wfB, afB);              // last sub-step of the previous step (zeros before the first one)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(wfB, afB);              // last sub-step of the previous step (zeros before the first one): landed before the barrier
+                __builtin_amdgcn_sched_barrier(0);
                 if (late) issue_dma();
                 load_set(1, wfB, afB);
+                brig_wait_lgkm<NR>();            // set A has landed, set B stays in flight under its MFMAs
                 mfma_set(wfA, afA);
                 if (NS == 4) {
                     load_set(2, wfA, afA);
+                    brig_wait_lgkm<NR>();
                     mfma_set(wfB, afB);
                     load_set(3, wfB, afB);
+                    brig_wait_lgkm<NR>();
                     mfma_set(wfA, afA);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         });
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     if (P2P_ABL != 1 && P2P_ABL != 4 && P2P_ABL != 5) mfma_set(wfB, afB);
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------------

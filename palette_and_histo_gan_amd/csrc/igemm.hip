@@ -447,24 +447,26 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
     constexpr int esz = sizeof(T);
     const int pixB = a.in_ld * esz, rowB = a.in_row * pixB;
 
-    // ---- staging: per-lane source addresses (row base + swizzled 16-byte slot); a K-block adds a wave-uniform offset --------------
-    const char* abq[NA];
-    int bbq[NB];
+    // ---- staging: 32-bit per-lane byte offsets (row base + swizzled 16-byte slot) from the lowest address a tap can reach (one
+    // row and one pixel in front of the view); a K-block adds a wave-uniform 64-bit base (p2p_glds16_sv: no vector address math) ----
+    const char* const in_lo = a.in - (rowB + pixB);
+    unsigned abq[NA];
+    unsigned bbq[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int r = (i * NW + wave) * 8 + (lane >> 3);
         const int m = min(m0 + r, a.M - 1);
         const int x = m & (a.LW - 1), y = (m >> a.lgLW) & (a.LH - 1), n = m >> (a.lgLW + a.lgLH);
         const int byy = MODE == 0 ? a.si * y - 1 : y, bxx = MODE == 0 ? a.si * x - 1 : x;
-        abq[i] = a.in + ((long long)n * a.in_img + (long long)byy * a.in_row + bxx) * pixB + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        abq[i] = (unsigned)(((long long)n * a.in_img + (long long)(byy + 1) * a.in_row + bxx + 1) * pixB + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int r = (j * NW + wave) * 8 + (lane >> 3);
-        bbq[j] = (n0 + r) * a.C * esz + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        bbq[j] = (unsigned)((n0 + r) * a.C * esz + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
     }
     const int wtap = a.w_rows * a.C * esz;
-    int s_aoff;                         // wave-uniform (scalar registers): offsets of the K-block being requested
+    const char* s_ak;                   // wave-uniform (scalar registers): bases of the K-block being requested
     const char* s_wk;
     auto stage_prepare = [&](int kb) {
         const int kbyte0 = kb << 7;
@@ -477,14 +479,16 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
             const int kh = (1 - ph) + 2 * (tl >> 1), kw = (1 - pw) + 2 * (tl & 1);
             dy = (ph + 1 - kh) >> 1; dx = (pw + 1 - kw) >> 1; widx = kh * 4 + kw;
         }
-        s_aoff = dy * rowB + dx * pixB + cb0;
+        s_ak = in_lo + (dy * rowB + dx * pixB + cb0);
         s_wk = a.w + ((long long)widx * wtap + cb0);
     };
+    const unsigned smem32 = p2p_lds32(smem);
     auto stage_piece = [&](char* buf, auto pc) {          // piece p (0 .. NL-1) of this wave
         constexpr int p = decltype(pc)::value;
         if (P2P_ABL == 2) return;
-        if constexpr (p < NA) glds16(abq[p] + s_aoff, buf + (p * NW + wave) * 1024);
-        else glds16(s_wk + bbq[p - NA], buf + A_BYTES + ((p - NA) * NW + wave) * 1024);
+        const unsigned dst = smem32 + (unsigned)(buf - smem);
+        if constexpr (p < NA) p2p_glds16_sv(s_ak, abq[p], dst + (p * NW + wave) * 1024);
+        else p2p_glds16_sv(s_wk, bbq[p - NA], dst + A_BYTES + ((p - NA) * NW + wave) * 1024);
     };
     auto stage_all = [&](int kb, char* buf) {
         stage_prepare(kb);
@@ -777,7 +781,10 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
     const int ctiles = (a.ncols + 31) / 32 * 32;      // launched columns (<= w_rows)
     const bool bigM = a.M >= 256 * 512;                // enough rows to fill the chip with 256-row tiles
     if constexpr (!GEN) {
-        if (igemm_pipe_mode() && a.lgCB >= 7 && ctiles % 128 == 0 && a.mode <= 1) {
+        // (32-bit per-lane gather offsets: the gathered view and the weights must each span less than 4 GB)
+        const long long in_span = ((long long)((a.M >> (a.lgLW + a.lgLH)) + 1) * a.in_img + 4LL * a.in_row + 4) * a.in_ld * (long long)sizeof(T);
+        const long long w_span = 16LL * a.w_rows * a.C * (long long)sizeof(T);
+        if (igemm_pipe_mode() && a.lgCB >= 7 && ctiles % 128 == 0 && a.mode <= 1 && in_span < 0xffffffffLL && w_span < 0xffffffffLL) {
             const bool ok = a.mode == 0 ? igemm_pipe_try<T, 0>(a, gz, vepi, st) : igemm_pipe_try<T, 1>(a, gz, vepi, st);
             if (ok) return p2p_check_launch("p2p_igemm");
         }

@@ -118,6 +118,21 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// LDS-DMA (global_load_lds_dwordx4) with a WAVE-UNIFORM 64-bit base in scalar registers and a 32-bit per-lane byte offset: the
+// saddr form of the instruction.  The builtin only takes a flat per-lane pointer, which costs a 64-bit vector add per piece
+// and keeps the per-lane offsets as 64-bit register pairs (r04: that pushed the block-resident kernel over 256 VGPRs).
+// `lds_dst` = wave-uniform LDS byte address of the piece (lane l lands at lds_dst + 16 l).  M0 is written and restored inside
+// the statement (cdna_hip_programming.md 5.7; the s_nop also covers a v_readfirstlane that wrote the base just before the
+// statement); the load is invisible to hipcc's wait-count bookkeeping: callers count vmcnt.
+__device__ __forceinline__ void p2p_glds16_sv(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned p2p_lds32(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 #define P2P_DISPATCH_DTYPE(dtype, CALL)                         \
     do {                                                        \
         if ((dtype) == P2P_F32) { typedef float T; CALL; }      \
