@@ -766,10 +766,13 @@ static bool igemm_pipe_try(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st)
     const int nkb = (a.taps_per * a.C * (int)sizeof(T)) >> 7;
     const int bm = igemm_bm(a.M, ctiles, gz);
     const int pm = igemm_pipe_mode();
-    if (bm == 256) { igemm_pipe_go<T, MODE, 4, 2, 2, 2, 1, 3>(a, gz, vepi, st); return true; }
+    // f32 (parity mode) without fused statistics: ONE variant whatever the pixel count, so that a pixel's sum does not depend on
+    // the batch it sits in (engine.batch_invariant)
+    const bool fixed = sizeof(T) == 4 && a.stat_part == nullptr && pm == 1;
+    if (bm == 256 && !fixed) { igemm_pipe_go<T, MODE, 4, 2, 2, 2, 1, 3>(a, gz, vepi, st); return true; }
     const long long tiles = ((a.M + 127) / 128) * (long long)(ctiles / 128) * gz;
     (void)nkb;
-    const bool kg2 = pm == 2 || (pm != 3 && tiles <= 384);      // one workgroup per CU anyway: the second wave of a SIMD splits K
+    const bool kg2 = fixed || pm == 2 || (pm != 3 && tiles <= 384);      // one workgroup per CU anyway: the second wave of a SIMD splits K
     if (kg2) igemm_pipe_go<T, MODE, 2, 2, 2, 2, 2, 4>(a, gz, vepi, st);
     else igemm_pipe_go<T, MODE, 2, 2, 2, 2, 1, 2>(a, gz, vepi, st);
     return true;
@@ -784,7 +787,11 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
         // (32-bit per-lane gather offsets: the gathered view and the weights must each span less than 4 GB)
         const long long in_span = ((long long)((a.M >> (a.lgLW + a.lgLH)) + 1) * a.in_img + 4LL * a.in_row + 4) * a.in_ld * (long long)sizeof(T);
         const long long w_span = 16LL * a.w_rows * a.C * (long long)sizeof(T);
-        if (igemm_pipe_mode() && a.lgCB >= 7 && ctiles % 128 == 0 && a.mode <= 1 && in_span < 0xffffffffLL && w_span < 0xffffffffLL) {
+        // diagnostics: P2P_IGEMM_PIPE_ONLY = "<mode><lgLW>" restricts the pipelined kernel to one op and map size (bisecting)
+        static int only = -2;
+        if (only == -2) { const char* e = getenv("P2P_IGEMM_PIPE_ONLY"); only = e ? atoi(e) : -1; }
+        const bool sel = only < 0 || only == a.mode * 10 + a.lgLW;
+        if (sel && igemm_pipe_mode() && a.lgCB >= 7 && ctiles % 128 == 0 && a.mode <= 1 && in_span < 0xffffffffLL && w_span < 0xffffffffLL) {
             const bool ok = a.mode == 0 ? igemm_pipe_try<T, 0>(a, gz, vepi, st) : igemm_pipe_try<T, 1>(a, gz, vepi, st);
             if (ok) return p2p_check_launch("p2p_igemm");
         }

@@ -386,6 +386,14 @@ class Pix2PixEngine:
         self.use_conv_strip = os.environ.get("P2P_CONV_STRIP", "1") != "0"      # up6 (32 <-> 128 channels): LDS strip, weights in registers
         self.use_conv_fewin = os.environ.get("P2P_CONV_FEWIN", "1") != "0"      # 8-channel inputs: weights in registers, strip in LDS
         self.wgemm_want = int(os.environ.get("P2P_WGEMM_WANT", "512"))     # workgroups wanted per 128x128-tile weight-gradient GEMM
+        # f32 (parity) mode is BATCH-INVARIANT on the data path: every per-image result (activations, data gradients) is produced
+        # by the same kernel variant, the same K split and the same statistics algorithm whatever the batch size, so an N-rank
+        # sharded step equals the 1-rank step image by image, bit for bit, and differs only in the order of the final weight-
+        # gradient sums.  (The heuristics below otherwise look at the batch: a 2+2 split of a batch of 4 then rounds differently,
+        # and one ReLU flip in the 1x1 .. 4x4 layers is enough to move Adam's first steps apart -- tests/test_dp_gpu.py.)
+        self.batch_invariant = dtype == L.F32 and os.environ.get("P2P_BATCH_INVARIANT", "1") != "0"
+        self.wgemm_pipe = os.environ.get("P2P_WGEMM_PIPE", "1") != "0"
+        self.wgemm_want_pipe = int(os.environ.get("P2P_WGEMM_WANT_PIPE", "256"))
         self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
         self._prep_table = {}
         self._head_prepped = False
@@ -647,6 +655,8 @@ class Pix2PixEngine:
 
     # -- heuristics for the MFMA kernels --------------------------------------------------------------
     def _splitk(self, op, B, lh, cg, cd):
+        if self.batch_invariant:
+            B = 256         # the K split of the benchmarked batch, whatever the batch
         ntaps = 16 if op == L.OP_G else 4
         if lh == 1:         # 1x1 maps: p2p_igemm contracts only the taps that meet real pixels (4 / 1 per phase)
             ntaps = 4 if op == L.OP_G else 1
@@ -670,6 +680,9 @@ class Pix2PixEngine:
         nw = 4 if nw >= 4 else nw
         tiles = 16 * ((cg + bg - 1) // bg) * ((cd + bd - 1) // bd)
         want = self.wgemm_want if nw == 4 else 4096 // nw
+        if self.dtype == L.BF16 and cg % 128 == 0 and cd % 128 == 0 and self.wgemm_pipe and tiles <= 448:
+            # the software-pipelined kernel: 8 waves and 128 KB of LDS per workgroup (one per CU), K split once more inside it
+            want = self.wgemm_want_pipe
         min_chunk = 256 if nw == 4 else 1024
         m = B * lh * lh
         ms = 1
@@ -721,7 +734,7 @@ class Pix2PixEngine:
         if self.use_mfma and lw.main and stride == 2 and bias is None and act == L.ACT_NONE and ncols is None:
             w = _p(lw.wt) if op == L.OP_G else self._wn(sid, name)
             if self.use_conv_strip and L.lib().p2p_conv_strip_ok(op, self.dtype, N, lh, lh, cg, cd):
-                slots = L.lib().p2p_conv_strip_stat_slots(op, self.dtype, N, lh, lh, cg, cd) if want_stats else 0
+                slots = L.lib().p2p_conv_strip_stat_slots(op, self.dtype, N, lh, lh, cg, cd) if (want_stats and not self.batch_invariant) else 0
                 if N * slots * cg * 2 > P["spart"].numel():
                     slots = 0
                 L.call("p2p_conv_strip", op, self.dtype, N, lh, lh, cg, cd, C.byref(hi), C.byref(lo), w,
@@ -729,7 +742,7 @@ class Pix2PixEngine:
                 return (1, 1, slots) if slots else (1, 1)
             sk = self._splitk(op, N, lh, cg, cd)
             slots = 0
-            if want_stats and sk == 1:      # InstanceNorm statistics fused into the GEMM epilogue
+            if want_stats and sk == 1 and not self.batch_invariant:      # InstanceNorm statistics fused into the GEMM epilogue
                 slots = L.lib().p2p_igemm_layer_stat_slots(op, self.dtype, N, lh, lh, cg, cd)
                 if N * slots * (cd if op == L.OP_G else cg) * 2 > P["spart"].numel():
                     slots = 0
@@ -857,6 +870,8 @@ class Pix2PixEngine:
         backward kernel (three input streams) when there would be fewer than ~1024 workgroups (4 per CU)."""
         if not bwd:
             return 1
+        if self.batch_invariant:
+            N = 256
         groups = max(1, c // 64)
         sp = 1
         while N * groups * sp < 1024 and res * res // (sp * 2) >= 64 and sp < 16:

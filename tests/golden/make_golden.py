@@ -59,6 +59,18 @@ def main():
         out[f"{tag}.d_loss"] = np.array(ref["d_loss"])
         summarise(ref["g_grads"], f"{tag}.G", out)
         summarise(ref["d_grads"], f"{tag}.D", out)
+        # the SAME oracle graph evaluated in float32: what f32 arithmetic itself does to this case's gradient samples (the yardstick
+        # of the engine's f32 mode; the histogram case holds near-black fake pixels whose gradient is 1 / (x + 1e-6)-steep)
+        f32 = torch.float32
+        r32 = rg.train_step_rgba({k: v.to(f32) for k, v in Gp.items()}, {k: v.to(f32) for k, v in Dp.items()},
+                                 torch.tensor(src, dtype=f32), torch.tensor(tgt, dtype=f32), [torch.tensor(m, dtype=f32) for m in masks],
+                                 lambda_l1=l1, lambda_hist=lh)
+        for k, g in r32["g_grads"].items():
+            a = g.numpy().reshape(-1).astype(np.float64)
+            want = out[f"{tag}.G.{k}.samples"]
+            scale = max(np.abs(want).max(), out[f"{tag}.G.{k}.abssum"] / a.size + 1e-30)
+            out[f"{tag}.G.{k}.f32dev"] = np.abs(a[sample_positions(k, a.size)] - want).max() / scale
+            out[f"{tag}.G.{k}.f32dev_abssum"] = abs(np.abs(a).sum() - out[f"{tag}.G.{k}.abssum"]) / (out[f"{tag}.G.{k}.abssum"] + 1e-300)
     # indexed model
     rng = np.random.default_rng(103)
     Gp = rg.perturb_affine(rg.init_params(rg.generator_param_shapes(1, 256), rng, F64), rng)

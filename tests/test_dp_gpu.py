@@ -175,10 +175,20 @@ def test_two_rank_fit_equals_one_rank_fit(tmp_path):
     assert sorted(os.listdir(ck_dir)) == [os.path.basename(ck_a[0])]
     # both ranks hold the same weights, and they are the 1-rank run's (f32 summation order, five Adam steps)
     assert np.array_equal(ga, gb) and np.array_equal(da, db)
-    # (Adam's first steps move every weight by ~lr whatever the gradient's size: an entry whose rounding-level gradient changes
-    # sign between the two summation orders moves by up to 2 lr = 4e-4 per step -- measured 4.3e-4 on a handful of entries)
-    assert np.abs(ga - g1).max() < 2e-3 and np.abs(da - d1).max() < 2e-3, (np.abs(ga - g1).max(), np.abs(da - d1).max())
-    assert np.abs(ga - g1).mean() < 2e-6, np.abs(ga - g1).mean()
+    # f32 mode is batch-invariant on the data path (engine.batch_invariant: same kernel variant, K split and statistics algorithm
+    # whatever the batch), so the two runs see bit-identical activations and data gradients and differ only in the order of the
+    # weight-gradient sums over the batch: a rounding-level gradient entry whose sign changes moves by up to 2 lr = 4e-4 in one
+    # Adam step (measured 4.3e-4 on a handful of entries, r03)
+    assert np.abs(ga - g1).max() < 6e-4 and np.abs(da - d1).max() < 6e-4, (np.abs(ga - g1).max(), np.abs(da - d1).max())
+    def worst():      # per-tensor report for a failing run
+        from palette_and_histo_gan_amd import engine as E_
+        offs, out = 0, []
+        for k, shp in E_.generator_param_shapes(4, 4).items():
+            n = int(np.prod(shp))
+            out.append((float(np.abs(ga[offs:offs + n] - g1[offs:offs + n]).mean()), k))
+            offs += (n + 3) // 4 * 4
+        return sorted(out, reverse=True)[:6]
+    assert np.abs(ga - g1).mean() < 2e-6, (np.abs(ga - g1).mean(), worst())
 
 
 @pytest.mark.timeout(600)

@@ -148,7 +148,11 @@ def test_conv_strip_up6(n, lh):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,msplit", [(2, 4, 32, 128, 1), (2, 8, 64, 128, 2), (3, 4, 128, 256, 1), (1, 1, 128, 128, 1),
-                                                (2, 16, 32, 128, 4), (5, 2, 64, 256, 1)])
+                                                (2, 16, 32, 128, 4), (5, 2, 64, 256, 1),
+                                                # whole 64-pixel stages, 128-multiple channels: the software-pipelined bf16 kernel
+                                                # (maps wider / narrower than a stage, 1x1 maps with dead taps, workgroups without pixels)
+                                                (4, 4, 128, 256, 1), (8, 8, 128, 128, 2), (64, 1, 128, 128, 1), (16, 2, 256, 128, 2),
+                                                (2, 16, 128, 128, 1), (1, 32, 128, 128, 4), (20, 4, 128, 128, 3)])
 def test_wgemm(dtype, n, lh, cg, cd, msplit):
     rng = np.random.default_rng(12)
     hi, lo, w = make_case(rng, n, lh, cg, cd, 2, dtype)

@@ -160,8 +160,12 @@ def test_engine_reproduces_golden_vectors():
             samples = gold[f"{tag}.G.{k}.samples"]
             got = a[mg.sample_positions(k, a.size)]
             scale = gold[f"{tag}.G.{k}.abssum"] / a.size + 1e-30
-            assert np.abs(got - samples).max() < 2e-2 * max(np.abs(samples).max(), scale), (tag, k)
-            assert abs(np.abs(a).sum() - gold[f"{tag}.G.{k}.abssum"]) <= 1e-3 * gold[f"{tag}.G.{k}.abssum"] + 1e-12, (tag, k)
+            # bound: 2 % of the tensor's scale, or 1.5 x what the ORACLE evaluated in float32 does to the same samples where that is more
+            # (histogram case: near-black fake pixels, gradient ~ 1 / (x + 1e-6); the f32 oracle is 2.6 % off on up3.kernel)
+            tol = max(2e-2, 1.5 * float(gold[f"{tag}.G.{k}.f32dev"]))
+            assert np.abs(got - samples).max() < tol * max(np.abs(samples).max(), scale), (tag, k)
+            tol_sum = max(1e-3, 1.5 * float(gold[f"{tag}.G.{k}.f32dev_abssum"]))
+            assert abs(np.abs(a).sum() - gold[f"{tag}.G.{k}.abssum"]) <= tol_sum * gold[f"{tag}.G.{k}.abssum"] + 1e-12, (tag, k)
     # argmax fixture, bit-exact
     p = torch.as_tensor(gold["argmax.probs"]).to("cuda:0")
     out = torch.empty(p.shape[0], dtype=torch.int32, device="cuda:0")

@@ -77,7 +77,8 @@ def test_c2_batch_256_f32_mode_against_the_f64_oracle():
     for k, e in {**eng_g, **{"D." + k: v for k, v in eng_d.items()}}.items():
         # f32 against f64 through 13 layers and a batch of 256: summation order plus the ReLU / LeakyReLU inputs that sit
         # within rounding of zero; the f32 ORACLE's own error on the same tensor is the yardstick
-        assert e <= max(1e-3, 4.0 * ora_g.get(k, 0.0)), (k, e, ora_g.get(k))
+        # (measured ratio engine / f32 oracle: 0.9 .. 1.2 on every tensor, profiles/r04_parity_evidence.json)
+        assert e <= max(1e-3, 1.5 * ora_g.get(k, 0.0)), (k, e, ora_g.get(k))
     wm, wl = grad_report(eng.G.export(eng.G.grads), ref["g_grads"])
     _record("c2_B256_worst", {"max_norm": wm, "l2": wl})
 
@@ -103,8 +104,8 @@ def test_c5_shape_histogram_model_128x128_against_the_f64_oracle():
     ora_g = _per_tensor_l2({k: v.numpy() for k, v in ref32["g_grads"].items()}, ref["g_grads"])
     _record("c5_shape_hist_B8_S128_f32_vs_f64_oracle", {"loss_rel_err": err.tolist(), "engine_grad_l2": eng_g, "oracle_f32_grad_l2": ora_g})
     assert err.max() <= 1e-4, err
-    for k, e in eng_g.items():       # yardstick as in the c2 test: the f32 oracle's own error on the same tensor (measured: both ~2e-3)
-        assert e <= max(1e-3, 4.0 * ora_g.get(k, 0.0)), (k, e, ora_g.get(k))
+    for k, e in eng_g.items():       # yardstick as in the c2 test: the f32 oracle's own error on the same tensor (measured ratio 0.9 .. 1.0)
+        assert e <= max(1e-3, 1.5 * ora_g.get(k, 0.0)), (k, e, ora_g.get(k))
 
 
 @pytest.mark.timeout(900)
