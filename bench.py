@@ -78,6 +78,21 @@ def cpu_baseline(model, S, lambda_l1, lambda_hist, budget_s=20.0):
                       f"({model} model), {el:.1f}s"}
 
 
+def _collective_info():
+    """what the gradient all-reduce of an N > 1 run actually went through: the driver's SCALE record then shows that RCCL saw N ranks
+    (no N > 1 RCCL curve exists from this build's one-GPU boxes)"""
+    import torch.distributed as dist
+    info = {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MAX_NCHANNELS") if k in os.environ}
+    if dist.is_available() and dist.is_initialized():
+        info["world_size"] = dist.get_world_size()
+        info["backend"] = dist.get_backend()
+        try:
+            info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # gloo rehearsal on a build without the binding
+            info["nccl_version"] = f"unavailable ({type(e).__name__})"
+    return info
+
+
 def kernel_profile(eng, run_step, n_steps=3):
     """Per-entry-point device time with HIP events on the launch stream, one event pair per C-ABI call."""
     records = []
@@ -216,8 +231,7 @@ def main():
                                   "RGBA sprites, " f"lambda_l1={lam_l1}") + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
                    "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if use_graph else "eager",
-                   **({"rccl": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MAX_NCHANNELS") if k in os.environ},
-                       "grad_buckets": len(eng.G.buckets)} if world > 1 else {})},
+                   **({"rccl": _collective_info(), "grad_buckets": len(eng.G.buckets)} if world > 1 else {})},
         "losses": [round(float(x), 5) for x in losses.cpu().numpy()],
     }
 

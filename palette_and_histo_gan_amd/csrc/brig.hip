@@ -552,11 +552,7 @@ static BrigPlan brig_plan(int op, int dtype, int N, int LH, int LW, int Cg, int 
     p.abytes = (p.npieces + 1) * 1024;         // one spare piece: tap offsets of clamped lanes stay inside the buffer
     p.nkc = (mode == 1 ? 1 : 4) * (C / 32);
     p.slots = p.tiles_per_img;
-    // weight ring: six stages where LDS allows (more slack between the DMA and its consumer), else four
-    static int ring_env = -1;
-    if (ring_env < 0) { const char* e = getenv("P2P_BRIG_RING"); ring_env = e ? atoi(e) : 0; }
-    p.ring = (ring_env == 4 || ring_env == 6) ? ring_env : 4;      // six stages measured no better than four (r02)
-    if (2 * (size_t)p.abytes + (size_t)p.ring * 16384 > 158 * 1024) p.ring = 4;
+    p.ring = 4;       // weight ring of four 16 KB stages (six measured no better, r02: that form and its switch are gone)
     p.shm = 2 * (size_t)p.abytes + (size_t)p.ring * 16384;
     const size_t epi = 8 * 32 * 144 + 8 * 2 * 64 * 2 * sizeof(float) + 4 * 256 * 2 * sizeof(float);
     if (p.shm < epi) p.shm = epi;
@@ -614,7 +610,7 @@ int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const 
     P2P_REQUIRE(span < 0xffffffffLL && (long long)16 * a.ncols * a.C * 2 < 0xffffffffLL, "p2p_brig: view larger than 4 GB");
     const dim3 grid((unsigned)(p.ntiles * p.nnt));
     hipStream_t st = (hipStream_t)stream;
-    const int key = (op == P2P_OP_P ? 4 : 0) + (p.cbw == 2 ? 2 : 0) + (p.ring == 6 ? 1 : 0);
+    const int key = (op == P2P_OP_P ? 2 : 0) + (p.cbw == 2 ? 1 : 0);
 #define BRIG_GO(M, CB, R)                                                                                                          \
     do {                                                                                                                           \
         static bool attr = false;                                                                                                  \
@@ -623,13 +619,9 @@ int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const 
     } while (0)
     switch (key) {
         case 0: BRIG_GO(0, 1, 4); break;
-        case 1: BRIG_GO(0, 1, 6); break;
-        case 2: BRIG_GO(0, 2, 4); break;
-        case 3: BRIG_GO(0, 2, 6); break;
-        case 4: BRIG_GO(1, 1, 4); break;
-        case 5: BRIG_GO(1, 1, 6); break;
-        case 6: BRIG_GO(1, 2, 4); break;
-        default: BRIG_GO(1, 2, 6); break;
+        case 1: BRIG_GO(0, 2, 4); break;
+        case 2: BRIG_GO(1, 1, 4); break;
+        default: BRIG_GO(1, 2, 4); break;
     }
 #undef BRIG_GO
     return p2p_check_launch("p2p_igemm(block-resident)");

@@ -307,31 +307,44 @@ __global__ __launch_bounds__(256) void head_bias_sum_kernel(const float* __restr
 }
 
 #include <stdlib.h>
-static int hs_rows() {       // output rows per workgroup: 4 (default; measured 0.289 ms at B = 128) or 2 (P2P_HEAD_ROWS=2: 0.428 ms --
-    static int v = -1;       // the overlap of two workgroups per CU does not pay for streaming the weights twice as often)
-    if (v < 0) { const char* e = getenv("P2P_HEAD_ROWS"); v = (e && atoi(e) == 2) ? 2 : 4; }
-    return v;
+// (one form: 4 output rows per workgroup.  The 2-row form -- two workgroups per CU -- streamed the weights twice as often and
+// measured 0.428 against 0.289 ms at B = 128, r03; it and its switch are gone.)
+
+// Both kernels of this file need the whole 160 KB of LDS of a gfx950 CU: the predicates answer 0 on a device that cannot give it,
+// so the engine falls back to p2p_igemm_edge + p2p_softmax_cce_argmax instead of failing at the launch.
+static bool hs_lds_ok(size_t need) {
+    static int max_lds = -1;
+    if (max_lds < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 0;
+        max_lds = v;
+    }
+    return (size_t)max_lds >= need;
 }
 
 extern "C" int p2p_head_softmax_ok(int dtype, int N, int H, int W, int cin_pad, int ncls) {
-    return dtype == P2P_BF16 && N > 0 && W == HS_W && H % 4 == 0 && cin_pad == HS_CIN && ncls == HS_NCLS;
+    return dtype == P2P_BF16 && N > 0 && W == HS_W && H % 4 == 0 && cin_pad == HS_CIN && ncls == HS_NCLS && hs_lds_ok(HsCfg<4, 5, 3>::SHM);
 }
 
 extern "C" long long p2p_head_softmax_workspace_bytes(int N, int H) {
-    const long long nwg = (long long)N * (H / 2);        // the 2-row form has the most workgroups
+    const long long nwg = (long long)N * (H / 2);        // (sized for 2-row workgroups: callers' buffers keep their size)
     return nwg * (HS_NCLS + 2) * (long long)sizeof(float);
 }
 
 template <int ROWS, int SS, int RING>
-static void hs_launch(const HsArgs& a, int nwg, hipStream_t st) {
+static int hs_launch(const HsArgs& a, int nwg, hipStream_t st) {
     typedef HsCfg<ROWS, SS, RING> K;
     static_assert(K::SHM <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)head_softmax_kernel<ROWS, SS, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SHM);
-        attr = true;
+    static int attr_dev = -1;      // the attribute is per device: set (and checked) again when the current device changes
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        const hipError_t e = hipFuncSetAttribute((const void*)head_softmax_kernel<ROWS, SS, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SHM);
+        P2P_REQUIRE(e == hipSuccess, "p2p_head_softmax_cce: %d bytes of dynamic LDS refused (%s)", (int)K::SHM, hipGetErrorString(e));
+        attr_dev = dev;
     }
     head_softmax_kernel<ROWS, SS, RING><<<dim3(nwg), dim3(K::NTHR), K::SHM, st>>>(a);
+    return 0;
 }
 
 extern "C" int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad, int ncls, const p2p_tensor* in, const void* wt,
@@ -349,15 +362,14 @@ extern "C" int p2p_head_softmax_cce(int dtype, int N, int H, int W, int cin_pad,
     a.target = (const bf16_t*)target->ptr; a.tg_img = target->img_stride; a.tg_row = target->row_stride; a.tg_ld = target->ld;
     a.fake = (bf16_t*)fake_idx->ptr; a.fk_img = fake_idx->img_stride; a.fk_row = fake_idx->row_stride; a.fk_ld = fake_idx->ld;
     a.dz = (char*)dz->ptr; a.dz_img = dz->img_stride; a.dz_row = dz->row_stride;
-    const int rows = hs_rows();
-    const int nwg = N * (H / rows);
+    const int nwg = N * (H / 4);
     a.loss_part = workspace;
     a.dbias_part = dbias ? workspace + 2 * (long long)nwg : nullptr;
     a.grad_scale = grad_scale; a.inv_count = inv_count; a.H = H;
     hipStream_t st = (hipStream_t)stream;
-    if (rows == 4) hs_launch<4, 5, 3>(a, nwg, st);
-    else hs_launch<2, 2, 3>(a, nwg, st);
-    int rc = p2p_check_launch("p2p_head_softmax_cce");
+    int rc = hs_launch<4, 5, 3>(a, nwg, st);
+    if (rc) return rc;
+    rc = p2p_check_launch("p2p_head_softmax_cce");
     if (rc) return rc;
     head_loss_sum_kernel<<<1, 256, 0, st>>>(a.loss_part, nwg, loss_out);
     if (dbias) head_bias_sum_kernel<<<dim3(HS_NCLS), 256, 0, st>>>(a.dbias_part, nwg, dbias);
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(512) void head_dgrad_kernel(HdArgs a) {
 
 extern "C" int p2p_head_dgrad_ok(int dtype, int N, int H, int W, int ncls, int cout, int w_rows, int dz_ld, int out_ld) {
     return dtype == P2P_BF16 && N > 0 && W == HS_W && H % HD_ROWS == 0 && ncls == HS_NCLS && cout == 32 && w_rows >= 32 &&
-           dz_ld == HS_NCLS && out_ld >= 32 && out_ld % 4 == 0;
+           dz_ld == HS_NCLS && out_ld >= 32 && out_ld % 4 == 0 && hs_lds_ok(2 * HD_STAGE);
 }
 
 extern "C" int p2p_head_dgrad(int dtype, int N, int H, int W, int ncls, int cout, const p2p_tensor* dz, const void* wn, int w_rows,
@@ -494,10 +506,13 @@ extern "C" int p2p_head_dgrad(int dtype, int N, int H, int W, int ncls, int cout
     a.H = H;
     constexpr int SHM = 2 * HD_STAGE;
     static_assert(SHM <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)head_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
-        attr = true;
+    static int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        const hipError_t e = hipFuncSetAttribute((const void*)head_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        P2P_REQUIRE(e == hipSuccess, "p2p_head_dgrad: %d bytes of dynamic LDS refused (%s)", (int)SHM, hipGetErrorString(e));
+        attr_dev = dev;
     }
     head_dgrad_kernel<<<dim3(N * (H / HD_ROWS)), dim3(512), SHM, (hipStream_t)stream>>>(a);
     return p2p_check_launch("p2p_head_dgrad");

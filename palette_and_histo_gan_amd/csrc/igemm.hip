@@ -698,12 +698,6 @@ static int igemm_bm(long long M, int ctiles, unsigned gz) {
     return M >= 256 * 512 ? 256 : 128;
 }
 
-static int igemm_stage_override() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("P2P_IGEMM_STAGES"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 template <typename T, int WM, int WN, int TM, int TN, bool GEN>
 static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
@@ -714,7 +708,6 @@ static void igemm_go(IgemmArgs& a, unsigned gz, bool vepi, hipStream_t st) {
     const long long nblk = (long long)grid.x * grid.y * grid.z;
     const int nkb_host = (a.taps_per * a.C * (int)sizeof(T)) >> 7;
     int nst = ((nblk <= 320 || NTHR == 512) && nkb_host >= 4) ? 3 : 2;   // 8-wave tiles: one workgroup per CU by design
-    if (igemm_stage_override() == 2 || igemm_stage_override() == 3) nst = igemm_stage_override();
     if (3 * (size_t)(BM + BN) * 128 > 150 * 1024) nst = 2;
     size_t stage = (size_t)nst * (BM + BN) * 128;
     size_t epi = (size_t)BM * (BN * 4 + 16) + 4096;    // f32 staging of the epilogue is the larger case (+ stats scratch)
@@ -787,11 +780,7 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
         // (32-bit per-lane gather offsets: the gathered view and the weights must each span less than 4 GB)
         const long long in_span = ((long long)((a.M >> (a.lgLW + a.lgLH)) + 1) * a.in_img + 4LL * a.in_row + 4) * a.in_ld * (long long)sizeof(T);
         const long long w_span = 16LL * a.w_rows * a.C * (long long)sizeof(T);
-        // diagnostics: P2P_IGEMM_PIPE_ONLY = "<mode><lgLW>" restricts the pipelined kernel to one op and map size (bisecting)
-        static int only = -2;
-        if (only == -2) { const char* e = getenv("P2P_IGEMM_PIPE_ONLY"); only = e ? atoi(e) : -1; }
-        const bool sel = only < 0 || only == a.mode * 10 + a.lgLW;
-        if (sel && igemm_pipe_mode() && a.lgCB >= 7 && ctiles % 128 == 0 && a.mode <= 1 && in_span < 0xffffffffLL && w_span < 0xffffffffLL) {
+        if (igemm_pipe_mode() && a.lgCB >= 7 && ctiles % 128 == 0 && a.mode <= 1 && in_span < 0xffffffffLL && w_span < 0xffffffffLL) {
             const bool ok = a.mode == 0 ? igemm_pipe_try<T, 0>(a, gz, vepi, st) : igemm_pipe_try<T, 1>(a, gz, vepi, st);
             if (ok) return p2p_check_launch("p2p_igemm");
         }

@@ -498,10 +498,8 @@ static int wgemm_launch(WgemmArgs& a, int msplit, hipStream_t st) {
         return p2p_check_launch("p2p_wgemm");
     }
     if (cd > 64) {
-        static int w8 = -1;
-        if (w8 < 0) { const char* e = getenv("P2P_WGEMM_W8"); w8 = e ? atoi(e) : 1; }     // eight waves (32x64 each) per 128x128 tile: -6.5 % on the kernel (r02 A/B), as in p2p_igemm
-        if (cg > 64 && w8) wgemm_go<T, 128, 128, 4, 2, 1, 2>(a, msplit, st);
-        else if (cg > 64) wgemm_go<T, 128, 128, 2, 2, 2, 2>(a, msplit, st);
+        // eight waves (32x64 each) per 128x128 tile: -6.5 % against four 64x64 waves in this (unpipelined) kernel, r02
+        if (cg > 64) wgemm_go<T, 128, 128, 4, 2, 1, 2>(a, msplit, st);
         else if (cg > 32) wgemm_go<T, 64, 128, 2, 2, 1, 2>(a, msplit, st);
         else wgemm_go<T, 32, 128, 1, 4, 1, 1>(a, msplit, st);
     } else if (cd > 32) {

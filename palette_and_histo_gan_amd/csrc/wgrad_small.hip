@@ -352,8 +352,7 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     }
     // strip height: the tallest of 8, 4, 2, 1 rows (<= 512 pixels) whose TWO buffers fit 150 KB (staging of the next strip under
     // the MFMAs of this one), unless that would leave strips of a single row where a single buffer allows >= 4 rows
-    static int dbuf = -1;
-    if (dbuf < 0) { const char* e = getenv("P2P_WS_DBUF"); dbuf = e ? atoi(e) : 0; }     // measured slower on c2 (r02: shorter strips, more halo): off
+    constexpr int dbuf = 0;      // double-buffered strips measured slower on c2 (r02: shorter strips, more halo); the kernel keeps the code path
     const size_t hpB = (size_t)hi_ld * esz > (size_t)64 * p.GT * (esz / 2) ? (size_t)64 * p.GT * (esz / 2) : (size_t)hi_ld * esz;
     const size_t lpB = (size_t)lo_ld * esz > (size_t)64 * p.DT * (esz / 2) ? (size_t)64 * p.DT * (esz / 2) : (size_t)lo_ld * esz;
     // bank swizzle (ws_swz) of the transposing reads: bf16, unpacked tiles, whole 64-byte quarters per pixel
@@ -379,10 +378,10 @@ static WsPlan ws_plan(int dtype, int stride, int N, int LH, int LW, int Cg, int 
     // few-channel (packed) layers: the contraction is a handful of MFMAs per strip, the kernel is a stream of strips.  One
     // workgroup per CU alternates "stage, wait, contract" and leaves HBM idle most of the time; several co-resident workgroups
     // (their strips are 53-71 KB, their partial slabs 4-32 KB) keep loads in flight while one of them contracts.
-    static int th_pack = -1, want_pack = -1, dbuf_pack = -1;
+    static int th_pack = -1, want_pack = -1;
+    constexpr int dbuf_pack = 0;
     if (th_pack < 0) { const char* e = getenv("P2P_WS_TH_PACK"); th_pack = e ? atoi(e) : 8; }
     if (want_pack < 0) { const char* e = getenv("P2P_WS_WANT_PACK"); want_pack = e ? atoi(e) : 512; }
-    if (dbuf_pack < 0) { const char* e = getenv("P2P_WS_DBUF_PACK"); dbuf_pack = e ? atoi(e) : 0; }
     if (p.pack && TH > th_pack) TH = th_pack;
     int th1 = 0, th2 = 0;       // tallest strip with one / two buffers
     for (int t = TH; t >= 1; t >>= 1) {

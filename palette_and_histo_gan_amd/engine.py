@@ -66,7 +66,8 @@ def _op(fn):
         _REC[0].append((None, fn, None))
 
 
-LIGHT_EVENTS = os.environ.get("P2P_LIGHT_EVENTS", "1") != "0"     # 0: torch.cuda.Event (system-scope release on every record)
+# (stream ordering always uses device-only events, p2p_event_*: torch.cuda.Event.record carries a system-scope release that idled
+# the main stream for ~6 us after every fork, r03; the torch fallback and its switch are gone)
 _EVENT_RING, _EVENT_NEXT = [], [0]
 _EVENT_RING_SIZE = 512            # far more than the stream operations of one step: an event is long consumed when its turn comes again
 
@@ -88,9 +89,6 @@ def _raw(stream):
 
 def _order(after, before):
     """work issued to stream `after` from now on waits for everything issued so far on stream `before`"""
-    if not LIGHT_EVENTS:
-        _op(lambda: after.wait_stream(before))
-        return
     ev, a, b = _ring_event(), _raw(after), _raw(before)
     rec, wait = L.lib().p2p_event_record, L.lib().p2p_stream_wait_event
 
@@ -121,15 +119,6 @@ class _SideStream:
             _order(torch.cuda.current_stream(), self.stream)
 
 
-class _TorchEvent:
-    def __init__(self, st):
-        self.ev = torch.cuda.Event()
-        _op(lambda: self.ev.record(st))
-
-    def wait(self, st):
-        _op(lambda: st.wait_event(self.ev))
-
-
 class _LightEvent:
     def __init__(self, st):
         self.ev = _ring_event()
@@ -151,7 +140,7 @@ class _LightEvent:
 
 def _record_event():
     """a new event recorded on the current stream (replayable)"""
-    return (_LightEvent if LIGHT_EVENTS else _TorchEvent)(torch.cuda.current_stream())
+    return _LightEvent(torch.cuda.current_stream())
 
 
 def _wait_event(ev):
@@ -351,7 +340,12 @@ class Pix2PixEngine:
         self.dtype, self.device, self.use_mfma = dtype, torch.device(device), use_mfma
         self.tdt = _torch_dtype(dtype)
         if self.device.type == "cuda":
-            _STREAM_DEVICE[0] = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            # the event ring, the raw stream query and the step recorder are process-wide and device-bound: one process drives one
+            # GPU (the data-parallel design) -- a second engine on another device is refused, not mis-ordered
+            if _STREAM_DEVICE[0] is not None and _STREAM_DEVICE[0] != idx and _EVENT_RING:
+                raise RuntimeError(f"this process already drives cuda:{_STREAM_DEVICE[0]}; one process per GPU (got cuda:{idx})")
+            _STREAM_DEVICE[0] = idx
         self.G = ParamStore(generator_param_shapes(in_ch, out_ch), self.device)
         self.D = ParamStore(discriminator_param_shapes(in_ch), self.device)
         # one allocation [G gradients | D gradients | 16 loss slots]: under data parallelism the generator's small-tensor
@@ -403,7 +397,7 @@ class Pix2PixEngine:
         self.fuse_act_bwd = int(os.environ.get("P2P_FUSE_ACT_BWD", "1"))   # D.last data gradient + LeakyReLU backward in one launch
         # Adam emitting the operand copies of the weights it updates (one pass, p2p_adam_prep_batched): measured 0.198 ms against
         # 0.187 ms for the flat Adam + batched copy launch on c2 (the tiled kernel streams slower than the flat one): off
-        self.fuse_adam = os.environ.get("P2P_FUSE_ADAM", "0") != "0"
+        self.fuse_adam = False      # (no environment switch: tests/test_train_step_gpu.py toggles the attribute)
         self._adam_tables = {}
         # host-side replay of the step's call list for launch-bound batches (see _REC above)
         self.replay_max_batch = int(os.environ.get("P2P_REPLAY_MAX_BATCH", "32"))
@@ -412,9 +406,10 @@ class Pix2PixEngine:
         self._slot_src, self._slot_real, self._slot_out = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._real_view = L.Tensor(None, 0, 0, 4)
         self.use_head_fused = os.environ.get("P2P_HEAD_FUSED", "1") != "0"    # indexed head: conv + softmax + CCE + argmax + gradient in one launch
-        self.hist_fwd3 = int(os.environ.get("P2P_HIST_FWD3", "1"))      # three shared kernel rows per pixel, all components in one workgroup
-        self.hist_bwd3 = int(os.environ.get("P2P_HIST_BWD3", "1"))      # backward: the three components in one workgroup, one gradient slab
-        self.hist_points = int(os.environ.get("P2P_HIST_POINTS", "1"))  # real image: contraction over its distinct colours
+        # histogram loss: three shared kernel rows per pixel with all components in one workgroup (forward and backward), the real
+        # image contracted over its distinct colours.  The per-component kernels remain in the library as cross-checks
+        # (tests/test_hist_indexed_gpu.py calls them directly); the engine has one path
+        self.hist_fwd3 = self.hist_bwd3 = self.hist_points = 1
         self.split_prep = int(os.environ.get("P2P_SPLIT_PREP", "1"))    # weight copies of the early-Adam part refreshed right behind it
         self.refresh_weight_copies()
 
@@ -941,9 +936,13 @@ class Pix2PixEngine:
         if (masks is not None or dp is not None or not apply_update or B > self.replay_max_batch or self.device.type != "cuda"
                 or L.call is not _ORIG_CALL or not self.replay_enabled or torch.cuda.is_current_stream_capturing()):
             return None
+        # everything the recorded calls hold BY VALUE: switches that choose kernels, the optimizer's hyper-parameters and the dropout
+        # seed (passed as scalars to p2p_adam_tick / p2p_adam_flat_dev / p2p_dropout_mask_dev), the K-split target and the stream the
+        # step was issued on (raw handles inside the recorded calls): a change of any of them records a new list
         return (kind, B, self.side.enabled, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
                 self.hist_points, self.fuse_act_bwd, self.split_prep, self.full_pixels, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
-                self.use_mfma) + extra
+                self.use_mfma, float(self.lr), float(self.beta1), float(self.beta2), float(self.adam_eps), int(self.seed),
+                int(self.splitk_target), int(self.wgemm_want), int(self.wgemm_want_pipe), int(torch.cuda.current_stream().cuda_stream)) + extra
 
     def _bind_batch(self, src_t, real_t):
         """the batch tensors of this step behind the re-usable pointer slots the recorded calls hold"""

@@ -179,7 +179,10 @@ class S2SModel(ABC):
         finally:
             if self.summary_writer is not None:
                 self.summary_writer.flush()
-            self._rank_barrier()        # nobody leaves fit() before rank 0 has written its last checkpoint and log rows
+        # success path only: nobody leaves fit() before rank 0 has written its last checkpoint and log rows.  A rank whose do_fit
+        # raised must NOT enter a barrier while its peers sit in gradient all-reduces (mismatched collectives hang until the
+        # timeout instead of surfacing the exception): it re-raises and the launcher tears the job down
+        self._rank_barrier()
 
     def do_fit(self, steps, update_steps=1000, callbacks=[], starting_step=0):
         """side2side_model.py:67-122"""

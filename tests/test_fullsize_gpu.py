@@ -112,3 +112,76 @@ def test_histogram_model_full_batch_c3():
         # the fused loss sees the f32 image that tanh produced; `fake` above went through the activation dtype
         assert abs(out[3] - hell) <= (1e-4 if dtype == L.F32 else 2e-2) * hell, (dtype, out[3], hell)
         assert np.isfinite(eng.G.grads.cpu().numpy()).all()
+
+
+@pytest.mark.timeout(1500)
+def test_c5_histogram_gradient_kernel_at_full_size():
+    """c5's per-GPU launch shape of the histogram kernels -- B = 256 images of 128x128 -- with VALUE
+    checks on the gradient (histogram.py:13-32,84-89 and its autodiff).  The Hellinger loss couples the batch through ONE scalar,
+    the sum of squares S over all images, so with the global S and the global batch size handed in
+      (a) a sub-batch launch of p2p_rgbuv_hist_hellinger_bwd3 must reproduce the full launch's gradient image by image, and
+      (b) the float64 oracle gives the same rows as the gradient of sqrt(S_sub + (S - S_sub)) / (sqrt(2) B) wrt the sub-batch."""
+    import ctypes as C
+    import math
+    from oracle import reference_graph as rg
+    B, S, SUBN = 256, 128, 4
+    rng = np.random.default_rng(63)
+    src, tgt = DU.synthetic_rgba_batch(rng, B, S, palette_size=24)
+    fake = np.clip(src + rng.normal(scale=0.05, size=src.shape), -1, 1).astype(np.float32)
+    st = U.stream()
+
+    def hists(img, points):
+        n = img.shape[0]
+        t = U.dev(img)
+        view = L.Tensor(t.data_ptr(), S * S, S, 4)
+        raw = torch.empty(n * 3 * 64 * 64, dtype=torch.float32, device=U.DEV)
+        ws = torch.empty(L.lib().p2p_rgbuv_hist_fwd3_workspace_bytes(n) // 4, dtype=torch.float32, device=U.DEV)
+        pts = torch.empty((n, 1024, 4), dtype=torch.float32, device=U.DEV)
+        npts = torch.zeros(n, dtype=torch.int32, device=U.DEV)
+        if points:
+            L.call("p2p_rgbuv_points", L.F32, n, S, S, C.byref(view), 1024, U.ptr(pts), U.ptr(npts), st)
+        L.call("p2p_rgbuv_hist_fwd3", L.F32, n, S, S, C.byref(view), U.ptr(pts) if points else None, U.ptr(npts) if points else None,
+               1024, U.ptr(raw), U.ptr(ws), st)
+        return t, view, raw
+
+    _, _, h_r = hists(tgt, True)
+    f_t, f_view, h_f = hists(fake, False)
+    tot = torch.empty((2, B), dtype=torch.float32, device=U.DEV)
+    sqp = torch.zeros(B, dtype=torch.float32, device=U.DEV)
+    sq = torch.zeros(4, dtype=torch.float32, device=U.DEV)
+    L.call("p2p_hellinger_fwd", U.ptr(h_r), U.ptr(h_f), B, U.ptr(tot[0]), U.ptr(tot[1]), U.ptr(sqp), U.ptr(sq), st)
+    coef = 1.0 / (2.0 * math.sqrt(2.0) * B)
+    gh = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=U.DEV)
+    dimg = torch.full((B * S * S * 4,), float("nan"), dtype=torch.float32, device=U.DEV)
+    L.call("p2p_rgbuv_hist_hellinger_bwd3", L.F32, B, S, S, C.byref(f_view), U.ptr(h_r), U.ptr(h_f), U.ptr(tot[0]), U.ptr(tot[1]),
+           U.ptr(sq), coef, U.ptr(gh), U.ptr(dimg), st)
+    torch.cuda.synchronize()
+    full = dimg.view(B, S, S, 4).cpu().numpy().astype(np.float64)
+    assert np.isfinite(full).all() and np.count_nonzero(full[..., 3]) == 0
+    sq_all = float(sqp.double().sum())
+    assert abs(float(sq[0]) - sq_all) <= 1e-6 * sq_all
+    H = 3 * 64 * 64
+    for k in (0, 37, 63):
+        sl = slice(k * SUBN, (k + 1) * SUBN)
+        # (a) the same kernel on the sub-batch, global sum and global batch size handed in
+        sub_t = U.dev(fake[sl])
+        sub_view = L.Tensor(sub_t.data_ptr(), S * S, S, 4)
+        tot_s = tot[:, sl].contiguous()
+        gh_s = torch.empty(SUBN * H, dtype=torch.float32, device=U.DEV)
+        d_s = torch.full((SUBN * S * S * 4,), float("nan"), dtype=torch.float32, device=U.DEV)
+        L.call("p2p_rgbuv_hist_hellinger_bwd3", L.F32, SUBN, S, S, C.byref(sub_view), U.ptr(h_r[k * SUBN * H:(k + 1) * SUBN * H]),
+               U.ptr(h_f[k * SUBN * H:(k + 1) * SUBN * H]), U.ptr(tot_s[0]), U.ptr(tot_s[1]), U.ptr(sq), coef, U.ptr(gh_s), U.ptr(d_s), st)
+        torch.cuda.synchronize()
+        sub = d_s.view(SUBN, S, S, 4).cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(sub - full[sl]) <= 1e-5 * np.linalg.norm(full[sl]), k
+        # (b) float64 oracle: gradient of sqrt(S_sub + const) / (sqrt(2) B) with const = S - S_sub
+        ft = torch.tensor(fake[sl], dtype=torch.float64, requires_grad=True)
+        hr = rg.rgbuv_histogram(torch.tensor(tgt[sl], dtype=torch.float64))
+        hf = rg.rgbuv_histogram(ft)
+        s_sub = ((torch.sqrt(hf) - torch.sqrt(hr)) ** 2).sum()
+        const = sq_all - float(s_sub)
+        loss = torch.sqrt(s_sub + const) / (math.sqrt(2.0) * B)
+        loss.backward()
+        ref = ft.grad.numpy()
+        assert np.linalg.norm(full[sl] - ref) <= 2e-3 * np.linalg.norm(ref), (k, np.linalg.norm(full[sl] - ref) / np.linalg.norm(ref))
+        assert U.rel_err(full[sl], ref) < 2e-3, k

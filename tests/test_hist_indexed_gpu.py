@@ -407,3 +407,60 @@ def test_indexed_model_train_step_matches_oracle():
     clear = (top2[..., 1] - top2[..., 0]) > 1e-5
     assert np.array_equal(idx[..., 0][clear], ref["fake_idx"].numpy()[..., 0][clear])
     assert clear.mean() > 0.99
+
+
+@pytest.mark.timeout(600)
+def test_fused_indexed_head_at_the_c4_launch_shape_against_the_generic_path():
+    """p2p_head_softmax_cce at c4's per-GPU launch shape (n = 128, 64x64, 33(+7) -> 256) against the generic path
+    on the SAME inputs -- p2p_igemm_edge (op G, stride 1, bias) writes the bf16 logits, p2p_softmax_cce_argmax takes softmax, CCE,
+    argmax and gradient from them.  The fused kernel never rounds the logits to bf16, so: loss to 2e-4, gradient to two bf16 steps
+    of its scale, identical argmax wherever the generic path's top two logits differ by more than the bf16 rounding of a logit
+    (pix2pix_model.py:268,273-293,300-301)."""
+    dtype, n, S, cin, cpad, Cn = L.BF16, 128, 64, 33, 40, 256
+    rng = np.random.default_rng(77)
+    x = U.q(rng.normal(size=(n, S, S, cin)).astype(np.float32), dtype)
+    w = U.q(0.08 * rng.normal(size=(4, 4, cin, Cn)), dtype)
+    bias = (0.1 * rng.normal(size=Cn)).astype(np.float32)
+    tgt = rng.integers(0, Cn, size=(n, S, S, 1)).astype(np.int32)
+    assert L.lib().p2p_head_softmax_ok(dtype, n, S, S, cpad, Cn)
+    xb = E.HaloBuf(n, S, S, cpad, dtype, U.DEV)
+    xb.t[:, 2:-2, 2:-2, :cin] = U.dev(x, U.tdt(dtype))
+    wt = np.zeros((16, Cn, cpad), np.float32)
+    wt[:, :, :cin] = w.reshape(16, cin, Cn).transpose(0, 2, 1)
+    wt_d, bias_d = U.dev(wt.reshape(-1), U.tdt(dtype)), U.dev(bias)
+    tb = E.HaloBuf(n, S, S, 8, dtype, U.DEV)
+    tb.t[:, 2:-2, 2:-2, :1] = U.dev(tgt.astype(np.float32), U.tdt(dtype))
+    inv, lam = 1.0 / (n * S * S), 0.01
+    # fused
+    fb, dz = E.HaloBuf(n, S, S, 8, dtype, U.DEV), E.HaloBuf(n, S, S, Cn, dtype, U.DEV)
+    ws = torch.zeros(L.lib().p2p_head_softmax_workspace_bytes(n, S) // 4 + 4, dtype=torch.float32, device=U.DEV)
+    loss, dbias = torch.zeros(2, dtype=torch.float32, device=U.DEV), torch.zeros(Cn, dtype=torch.float32, device=U.DEV)
+    L.call("p2p_head_softmax_cce", dtype, n, S, S, cpad, Cn, C.byref(xb.view()), U.ptr(wt_d), U.ptr(bias_d), C.byref(tb.view()),
+           C.byref(fb.view()), lam * inv, inv, C.byref(dz.view()), U.ptr(dbias), U.ptr(ws), U.ptr(loss), U.stream())
+    # generic: logits in bf16, then softmax / CCE / argmax / gradient
+    zb = E.DenseBuf(n, S, S, Cn, U.tdt(dtype), U.DEV)
+    L.call("p2p_igemm_edge", L.OP_G, 1, dtype, n, S, S, cpad, Cn, Cn, C.byref(xb.view()), C.byref(zb.view()), U.ptr(wt_d), U.ptr(bias_d),
+           L.ACT_NONE, 0.3, U.stream())
+    fb2, dz2 = E.HaloBuf(n, S, S, 8, dtype, U.DEV), E.HaloBuf(n, S, S, Cn, dtype, U.DEV)
+    part = torch.zeros(2 * 8192, dtype=torch.float32, device=U.DEV)
+    loss2 = torch.zeros(2, dtype=torch.float32, device=U.DEV)
+    L.call("p2p_softmax_cce_argmax", dtype, n, S, S, Cn, C.byref(zb.view()), C.byref(tb.view()), C.byref(fb2.view()), lam * inv, inv,
+           C.byref(dz2.view()), None, U.ptr(part), U.ptr(loss2), U.stream())
+    torch.cuda.synchronize()
+    l1, l2 = loss.cpu().numpy(), loss2.cpu().numpy()
+    assert abs(l1[0] - l2[0]) < 2e-4 * abs(l2[0]), (l1, l2)
+    assert abs(l1[1] - l2[1]) < 2e-4 * abs(l2[1]) + 1e-7, (l1, l2)
+    g1 = dz.t[:, 2:-2, 2:-2, :].float()
+    g2 = dz2.t[:, 2:-2, 2:-2, :].float()
+    scale = float(g2.abs().max())
+    assert float((g1 - g2).abs().max()) < 2.0 ** -6 * scale          # the bf16 logits of the generic path move a probability by ~2^-8 of itself
+    assert float(torch.linalg.vector_norm(g1 - g2) / torch.linalg.vector_norm(g2)) < 2e-2
+    # bias gradient of the fused kernel = column sums of ITS stored gradient
+    np.testing.assert_allclose(dbias.cpu().numpy(), g1.double().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=2e-4, atol=1e-6)
+    i1 = fb.t[:, 2:-2, 2:-2, 0].float()
+    i2 = fb2.t[:, 2:-2, 2:-2, 0].float()
+    z = zb.t.view(n, S, S, Cn).float()
+    top2 = torch.topk(z, 2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 2.0 ** -6 * top2[..., 0].abs().clamp_min(1.0)       # beyond the rounding of a bf16 logit
+    assert bool((i1 == i2)[clear].all()) and float(clear.float().mean()) > 0.8
+    assert float((i1 == i2).float().mean()) > 0.98

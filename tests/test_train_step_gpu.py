@@ -329,3 +329,37 @@ def test_train_step_128x128_sprites_f32():
     print("worst G", wg, "worst D", wd)
     assert float(np.abs(ref["g_grads"]["down6.kernel"].numpy()).max()) > 0.0        # live at S = 128
     assert wg[1][1] < 2e-3 and wd[1][1] < 1e-4
+
+
+def test_step_replay_follows_hyper_parameters_and_the_current_stream():
+    """a recorded call list holds lr / beta / epsilon / seed and raw stream handles by value.  Changing the
+    learning rate, or issuing the step under another torch stream, after a step has been recorded must give what the eager engine
+    gives -- the key of a replay covers them, so the changed step is recorded anew instead of replaying stale arguments."""
+    from palette_and_histo_gan_amd import dataset_utils as DU
+    B, S = 4, 64
+    batches = list(DU.synthetic_rgba_ds(32, batch_size=B, palette_size=24, seed=4))
+    other = torch.cuda.Stream()
+    runs = []
+    for replay in (True, False):
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, L.BF16, seed=5)
+        eng.replay_enabled = replay
+        losses = []
+        for t, b in enumerate(batches):
+            if t == 4:
+                eng.lr = 5e-4                       # picked up by p2p_adam_tick of this and the following steps
+            if t >= 6:                              # the last steps run under a side stream of the caller
+                other.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(other):
+                    losses.append(eng.train_step_rgba(b[0], b[1], 100.0))
+                torch.cuda.current_stream().wait_stream(other)
+            else:
+                losses.append(eng.train_step_rgba(b[0], b[1], 100.0))
+        torch.cuda.synchronize()
+        if replay:
+            assert len(eng._replays) == 3           # (lr 2e-4, default stream), (lr 5e-4, default stream), (lr 5e-4, side stream)
+        runs.append((torch.stack([x.cpu() for x in losses]), eng))
+    (la, a), (lb, b) = runs
+    assert torch.equal(la, lb), (la - lb).abs().max()
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        for buf in ("params", "m", "v"):
+            assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
