@@ -443,24 +443,38 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
 }
 
 // ---- backward, all three components of an image in one workgroup ---------------------------------------------------------
-// Measured model of these kernels (r03 PMC + timing): v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and does not overlap
-// with the other waves' vector instructions on its SIMD -- kernel time = (matrix cycles + vector cycles) per SIMD.  The lever is
-// the vector instruction count per pixel, on evenly loaded SIMDs.  As in rgbuv_hist_fwd3_kernel the three kernel rows ka, kb, kc
-// of the log-chroma differences a = lR - lG, b = lR - lB, c = lG - lB (and their mirror images) serve every product of the
-// closed form: component R has (u, v) = (a, b), G has (-a, c), B has (-b, -c).  Twelve waves = (component, product, row tile):
-// product 0 = GH kv (paired with ku: dIy and du), product 1 = GH^T ku (paired with kv: dv); three waves per SIMD.  Per batch
-// of 64 pixels every kernel row is evaluated once (3 x 64 x 64 values instead of 3 x 2 x 64 x 64), the pixel's logarithms once
-// instead of three times, the epilogue keeps two running sums per pixel (sum D k, sum D k^2 (coord - d)) with the bin
-// centres in registers, and the three components' pixel gradients are combined here: ONE f32 slab leaves.
+// Round 3 ran this contraction on v_mfma_f32_32x32x2_f32: that instruction runs at the f32 VECTOR rate (1/16 of the bf16 matrix
+// rate) and, measured, never overlaps with the other waves' vector instructions on its SIMD -- kernel time = matrix cycles +
+// vector cycles, two thirds of it matrix cycles (r03 PMC: MFMA-busy 48 %, VALU 45 %).  Round 4: the SAME f32 products on the bf16
+// matrix pipe by three-way splitting.  Every f32 operand x is written as x1 + x2 + x3, each part the bf16 rounding of what the
+// previous parts left (3 x 8 = 24 significant bits: the sum reproduces x to <= 2^-24 |x|); a product a b is taken as the six
+// partial products a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2 (everything above 2^-24 of |a b|; each bf16 x bf16 product is exact in
+// f32) accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Six instructions at 16x the rate: 2.7x fewer matrix cycles for a result
+// that differs from the f32 fma chain by rounding-level terms (tests: same bounds as before against the float64 oracle, and 1e-4
+// against the per-component f32-MFMA kernel kept as the cross-check).
+// Structure as in round 3: the three kernel rows ka, kb, kc of the log-chroma differences a = lR - lG, b = lR - lB, c = lG - lB
+// serve every product of the closed form (component R has (u, v) = (a, b), G has (-a, c), B has (-b, -c); the bin grid is symmetric,
+// so a mirrored coordinate is a flip of the GRADIENT matrix's index, applied once when it is loaded); twelve waves = (component,
+// product, row tile): product 0 = GH kv (paired with ku: dIy and du), product 1 = GH^T ku (paired with kv: dv).  New: the wave's
+// 32 x 64 slice of GH (constant over the image) lives in REGISTERS as MFMA A fragments (3 parts x 4 k-steps), so the loop reads only
+// the kernel rows from LDS: [part][row][pixel][bin] bf16, 16-byte chunks XOR-swizzled by the pixel (conflict-free ds_read_b128).
 #define B3_PB 64
 #define B3_NT 768
+#define B3_KIMG (3 * 3 * B3_PB * HB * 2)      // bytes of the split kernel-row image
+
+__device__ __forceinline__ void split3(float x, bf16_t& p1, bf16_t& p2, bf16_t& p3) {
+    p1 = (bf16_t)x;
+    const float r1 = x - (float)p1;
+    p2 = (bf16_t)r1;
+    p3 = (bf16_t)(r1 - (float)p2);
+}
+
 template <typename T>
 __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TView img, const float* __restrict__ gh,
                                                                float* __restrict__ dimg, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) char b3_smem[];
-    float (*G)[HB][HB + 1] = (float (*)[HB][HB + 1])b3_smem;                         // [3][64][65]
-    float (*K3)[HB][B3_PB] = (float (*)[HB][B3_PB])(b3_smem + 3 * HB * (HB + 1) * 4); // ka, kb, kc as [bin][pixel]
-    float* fl = (float*)(b3_smem + 3 * HB * (HB + 1) * 4 + 3 * HB * B3_PB * 4);
+    char* const Kimg = b3_smem;                                                      // [3 parts][3 rows a, b, c][64 pixels][64 bins] bf16
+    float* fl = (float*)(b3_smem + B3_KIMG);
     float (*sco)[B3_PB] = (float (*)[B3_PB])fl;               // [3] a, b, c
     float* siy = fl + 3 * B3_PB;
     float (*sx)[4] = (float (*)[4])(siy + B3_PB);             // [PB][4]
@@ -472,22 +486,36 @@ __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TV
     int chunk = (HW + nsplit - 1) / nsplit;
     chunk = (chunk + B3_PB - 1) / B3_PB * B3_PB;
     const int q0 = ps * chunk, q1 = min(HW, q0 + chunk);
-    for (int idx = tid; idx < 3 * HB * HB; idx += B3_NT) {
-        const int c = idx >> 12, ij = idx & 4095;
-        G[c][ij >> 6][ij & 63] = gh[((long long)n * 3 + c) * HB * HB + ij];
-    }
     const int c = wave >> 2, prod = (wave >> 1) & 1, rt = wave & 1;
-    // (u, v) of component c in terms of the shared rows: array index, mirrored?
+    // (u, v) of component c in terms of the shared rows: row index, mirrored?
     const int ua = c == 2 ? 1 : 0, va = c == 0 ? 1 : 2;
     const bool um = c != 0, vm = c == 2;
-    const int ra = prod == 0 ? va : ua, oa = prod == 0 ? ua : va;          // right-hand rows / the rows the result is paired with
-    const bool rm = prod == 0 ? vm : um, om = prod == 0 ? um : vm;
+    const int ra = prod == 0 ? va : ua, oa = prod == 0 ? ua : va;          // contracted rows / the rows the result is paired with
+    const bool om = prod == 0 ? um : vm;
     const float osign = om ? -1.f : 1.f;
     const int li = lane & 31, hk = lane >> 5;
-    const int row = rt * 32 + li;
-    float dcen[16];                                          // bin centres of this lane's 16 result rows
+
+    // ---- this wave's slice of the gradient matrix as A fragments: GH'[i'][j'] = GH_c[um ? 63 - i' : i'][vm ? 63 - j' : j'];
+    // product 0: A[row][k] = GH'[rt*32 + row][k],  product 1: A[row][k] = GH'[k][rt*32 + row]   (lane: row = li, k = 16 s + 8 hk + e)
+    bf16x8 ga[3][4];
+    {
+        const float* g = gh + ((long long)n * 3 + c) * HB * HB;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dcen[e] = hist_center(rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk);
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 16 * s4 + 8 * hk + e, rr = rt * 32 + li;
+                const int ip = prod == 0 ? rr : kk, jp = prod == 0 ? kk : rr;
+                const float v = g[(um ? 63 - ip : ip) * HB + (vm ? 63 - jp : jp)];
+                bf16_t p1, p2, p3;
+                split3(v, p1, p2, p3);
+                ga[0][s4][e] = p1; ga[1][s4][e] = p2; ga[2][s4][e] = p3;
+            }
+    }
+    const float cen0 = hist_center(rt * 32 + 4 * hk);       // centre of this lane's first result row; row e lies (e&3) + 8 (e>>2) bins on
+    // byte offset of (row, pixel, 16-byte chunk) inside one part of the kernel-row image
+    auto koff = [](int row, int p, int ch) { return (row * B3_PB + p) * (HB * 2) + ((ch ^ ((p >> 1) & 7)) << 4); };
+    constexpr int KPART = 3 * B3_PB * HB * 2;
     for (int p0 = q0; p0 < q1; p0 += B3_PB) {
         __syncthreads();
         if (tid < B3_PB) {
@@ -503,10 +531,21 @@ __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TV
             sx[tid][0] = x[0]; sx[tid][1] = x[1]; sx[tid][2] = x[2];
         }
         __syncthreads();
-        for (int idx = tid; idx < 3 * HB * B3_PB; idx += B3_NT) {
-            const int r = idx / (HB * B3_PB), rem = idx - r * (HB * B3_PB);
-            const int i = rem / B3_PB, p = rem - i * B3_PB;
-            K3[r][i][p] = iq_kernel(sco[r][p] - hist_center(i));
+        // kernel rows, split: one 16-byte chunk (8 bins of one pixel) of each part per item
+        for (int idx = tid; idx < 3 * B3_PB * 8; idx += B3_NT) {
+            const int r = idx >> 9, p = (idx >> 3) & 63, ch = idx & 7;
+            const float co = sco[r][p];
+            bf16x8 k1, k2, k3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bf16_t q1b, q2b, q3b;
+                split3(iq_kernel(co - hist_center(ch * 8 + e)), q1b, q2b, q3b);
+                k1[e] = q1b; k2[e] = q2b; k3[e] = q3b;
+            }
+            const int o = koff(r, p, ch);
+            *(bf16x8*)(Kimg + o) = k1;
+            *(bf16x8*)(Kimg + KPART + o) = k2;
+            *(bf16x8*)(Kimg + 2 * KPART + o) = k3;
         }
         __syncthreads();
         f32x16 acc[2];
@@ -514,32 +553,49 @@ __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TV
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-#pragma unroll 8
-        for (int kk = 0; kk < HB / 2; ++kk) {
-            const int k = 2 * kk + hk;
-            const float av = prod == 0 ? G[c][row][k] : G[c][k][row];
-            const float* br = K3[ra][rm ? 63 - k : k];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br[li], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br[32 + li], acc[1], 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            bf16x8 kb[3][2];                                  // B fragments: [part][pixel tile]: pixel = t*32 + li, bins 16 s + 8 hk ..
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) kb[part][t] = *(const bf16x8*)(Kimg + part * KPART + koff(ra, t * 32 + li, 2 * s4 + hk));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // smallest partial products first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1][s4], kb[1][t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2][s4], kb[0][t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0][s4], kb[2][t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1][s4], kb[0][t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0][s4], kb[1][t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0][s4], kb[0][t], acc[t], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pcol = j * 32 + li;
-            const float cval = osign * sco[oa][pcol];    // u or v of this component at the lane's pixel
+            const float cval = sco[oa][pcol] - cen0;     // a, b or c at the lane's pixel minus the first row's centre (the mirror is the sign `osign`)
             float s0 = 0.f, s1 = 0.f;                    // sum D k,  sum D k^2 (coord - d)
+            typedef __attribute__((__vector_size__(4 * sizeof(bf16_t)))) bf16_t bf16x4;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r2 = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
-                const float kq = K3[oa][om ? 63 - r2 : r2][pcol];
-                const float w = acc[j][e] * kq;
-                s0 += w;
-                s1 = fmaf(w * kq, cval - dcen[e], s1);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // rows rt*32 + 8 g4 + 4 hk + 0..3 = bins of chunk rt*4 + g4, second half for hk = 1
+                const int o = koff(oa, pcol, rt * 4 + g4) + 8 * hk;
+                const bf16x4 v1 = *(const bf16x4*)(Kimg + o), v2 = *(const bf16x4*)(Kimg + KPART + o), v3 = *(const bf16x4*)(Kimg + 2 * KPART + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * g4 + k;
+                    const float kq = ((float)v1[k] + (float)v2[k]) + (float)v3[k];
+                    const float w = acc[j][e] * kq;
+                    s0 += w;
+                    s1 = fmaf(w * kq, cval - (float)((e & 3) + 8 * (e >> 2)) * (6.0f / 63.0f), s1);
+                }
             }
             s0 += __shfl_xor(s0, 32, 64);
             s1 += __shfl_xor(s1, 32, 64);
             if (hk == 0) {
-                // sum_rows D g(t) k^2 with g(t) = -2 (coord - d) / sigma^2
-                const float part1 = (-2.0f * INV_SIGMA2) * s1 * siy[pcol];
+                // sum_rows D g(t) k^2 with g(t) = -2 (coord - d) / sigma^2, coord - d = osign (shared coordinate - mirrored centre)
+                const float part1 = (-2.0f * INV_SIGMA2) * osign * s1 * siy[pcol];
                 if (prod == 0) { racc[c][rt][0][pcol] = s0; racc[c][rt][1][pcol] = part1; }
                 else { racc[c][rt][2][pcol] = part1; }
             }
@@ -643,7 +699,7 @@ extern "C" int p2p_rgbuv_hist_hellinger_bwd3(int dtype, int N, int H, int W, con
     if (rc) return rc;
     int nsplit = 1;
     while (N * nsplit < 256 && (H * W) / (nsplit * 2) >= 8 * B3_PB) nsplit *= 2;       // one 12-wave workgroup per CU
-    constexpr int SHM = (3 * HB * (HB + 1) + 3 * HB * B3_PB + 3 * B3_PB + B3_PB + 4 * B3_PB + 18 * B3_PB) * 4;
+    constexpr int SHM = B3_KIMG + (3 * B3_PB + B3_PB + 4 * B3_PB + 18 * B3_PB) * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)rgbuv_hist_bwd3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
