@@ -187,17 +187,35 @@ __global__ __launch_bounds__(256) void rgbuv_points_kernel(int H, int W, TView i
 //     H_R[i][j] = sum Iy ka[i]    kb[j]        H_G[i][j] = sum Iy ka[63-i] kc[j]        H_B[i][j] = sum Iy kb[63-i] kc[63-j]
 // grid = (image, pixel range): each workgroup contracts its range of pixels -- or of the image's colour points (weights =
 // pixel counts) -- and writes one partial [3][64][64]; rgbuv_hist_fold_kernel adds the ranges in order.
-#define H3_PB 48
+// Round 4: the contraction runs on the bf16 matrix pipe by three-way operand splitting (see rgbuv_hist_bwd3_kernel: x = x1 + x2 + x3
+// in bf16 parts, six partial products, f32 accumulate) instead of v_mfma_f32_32x32x2_f32 (f32 vector rate).  Twelve waves =
+// (component, row tile, column tile), one 32x32 accumulator each; the four operand arrays Iy ka, Iy kb (rows) and kb, kc (columns)
+// live in LDS as [part][array][bin][pixel] bf16 -- the contraction index (pixel) contiguous, 16-byte chunks XOR-swizzled by the bin --
+// so a mirrored bin index (63 - i) is just another row address.
+#define H3_PB 64
 #define H3_PS 3
+#define H3_NT 768
+#define H3_ARR (HB * H3_PB * 2)               // bytes of one part of one array
+#define H3_KIMG (3 * 4 * H3_ARR)
+
+__device__ __forceinline__ void split3(float x, bf16_t& p1, bf16_t& p2, bf16_t& p3) {
+    p1 = (bf16_t)x;
+    const float r1 = x - (float)p1;
+    p2 = (bf16_t)r1;
+    p3 = (bf16_t)(r1 - (float)p2);
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void rgbuv_hist_fwd3_kernel(int H, int W, TView img, const f32x4* __restrict__ points,
-                                                             const int* __restrict__ npoints, int cap, float* __restrict__ part) {
-    __shared__ float Aa[H3_PB][HB], Ab[H3_PB][HB];      // Iy*w*ka, Iy*w*kb   (row operands)
-    __shared__ float Bb[H3_PB][HB], Bc[H3_PB][HB];      // kb, kc             (column operands)
-    __shared__ float sa[H3_PB], sb[H3_PB], sc[H3_PB], siy[H3_PB];
+__global__ __launch_bounds__(H3_NT) void rgbuv_hist_fwd3_kernel(int H, int W, TView img, const f32x4* __restrict__ points,
+                                                               const int* __restrict__ npoints, int cap, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char h3_smem[];
+    char* const Kimg = h3_smem;                             // [3 parts][4 arrays: Iy ka, Iy kb, kb, kc][64 bins][64 pixels] bf16
+    float* const sa = (float*)(h3_smem + H3_KIMG);
+    float* const sb = sa + H3_PB; float* const sc = sb + H3_PB; float* const siy = sc + H3_PB;
     const int n = blockIdx.x, ps = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ti = wave >> 1, tj = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = wave >> 2, ti = (wave >> 1) & 1, tj = wave & 1;
     const int HW = H * W;
     const int np = (points && npoints) ? npoints[n] : -1;
     const bool listed = np >= 0;
@@ -205,15 +223,21 @@ __global__ __launch_bounds__(256) void rgbuv_hist_fwd3_kernel(int H, int W, TVie
     int chunk = (total + H3_PS - 1) / H3_PS;
     chunk = (chunk + H3_PB - 1) / H3_PB * H3_PB;
     const int q0 = ps * chunk, q1 = min(total, q0 + chunk);
-    f32x16 acc[3];
+    // byte offset of (array, bin, 16-byte chunk of 8 pixels) inside one part
+    auto koff = [](int arr, int bin, int ch) { return arr * H3_ARR + bin * (H3_PB * 2) + ((ch ^ ((bin >> 1) & 7)) << 4); };
+    // component c: H_R = (Iy ka)[i] kb[j],  H_G = (Iy ka)[63-i] kc[j],  H_B = (Iy kb)[63-i] kc[63-j]
+    const int li = lane & 31, hk = lane >> 5;
+    const int ci = ti * 32 + li, cj = tj * 32 + li;
+    const int arow = c == 2 ? 1 : 0, abin = c == 0 ? ci : 63 - ci;
+    const int brow = c == 0 ? 2 : 3, bbin = c == 2 ? 63 - cj : cj;
+    f32x16 acc;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int p0 = q0; p0 < q1; p0 += H3_PB) {
+        __syncthreads();                                    // the previous batch's fragments have been read
         if (tid < H3_PB) {
             const int p = p0 + tid;
-            float a = 0.f, b = 0.f, c = 0.f, iy = 0.f;
+            float a = 0.f, b = 0.f, cc = 0.f, iy = 0.f;
             if (p < q1) {
                 float x[3], wgt = 1.f;
                 if (listed) {
@@ -225,37 +249,61 @@ __global__ __launch_bounds__(256) void rgbuv_hist_fwd3_kernel(int H, int W, TVie
                 }
                 iy = wgt * sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + HIST_EPS);
                 const float lr = logf(x[0] + HIST_EPS), lg = logf(x[1] + HIST_EPS), lb = logf(x[2] + HIST_EPS);
-                a = lr - lg; b = lr - lb; c = lg - lb;
+                a = lr - lg; b = lr - lb; cc = lg - lb;
             }
-            sa[tid] = a; sb[tid] = b; sc[tid] = c; siy[tid] = iy;       // iy = 0 beyond the range: contributes nothing
+            sa[tid] = a; sb[tid] = b; sc[tid] = cc; siy[tid] = iy;       // iy = 0 beyond the range: contributes nothing
         }
         __syncthreads();
-        for (int idx = tid; idx < H3_PB * HB; idx += 256) {
-            const int p = idx >> 6, i = idx & 63;
-            const float d = hist_center(i), iy = siy[p];
-            const float ka = iq_kernel(sa[p] - d), kb = iq_kernel(sb[p] - d), kc = iq_kernel(sc[p] - d);
-            Aa[p][i] = iy * ka; Ab[p][i] = iy * kb; Bb[p][i] = kb; Bc[p][i] = kc;
+        // one item = (row type a / b / c, bin, chunk of 8 pixels): evaluate the kernel row, split, store
+        for (int idx = tid; idx < 3 * HB * (H3_PB / 8); idx += H3_NT) {
+            const int rty = idx >> 9, bin = (idx >> 3) & 63, ch = idx & 7;
+            const float d = hist_center(bin);
+            const float* co = rty == 0 ? sa : (rty == 1 ? sb : sc);
+            bf16x8 w1, w2, w3, k1, k2, k3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int p = ch * 8 + e;
+                const float k = iq_kernel(co[p] - d);
+                bf16_t q1b, q2b, q3b;
+                split3(k, q1b, q2b, q3b);
+                k1[e] = q1b; k2[e] = q2b; k3[e] = q3b;
+                split3(siy[p] * k, q1b, q2b, q3b);
+                w1[e] = q1b; w2[e] = q2b; w3[e] = q3b;
+            }
+            if (rty <= 1) {                   // Iy ka -> array 0, Iy kb -> array 1
+                const int o = koff(rty, bin, ch);
+                *(bf16x8*)(Kimg + o) = w1; *(bf16x8*)(Kimg + 4 * H3_ARR + o) = w2; *(bf16x8*)(Kimg + 8 * H3_ARR + o) = w3;
+            }
+            if (rty >= 1) {                   // kb -> array 2, kc -> array 3
+                const int o = koff(rty + 1, bin, ch);
+                *(bf16x8*)(Kimg + o) = k1; *(bf16x8*)(Kimg + 4 * H3_ARR + o) = k2; *(bf16x8*)(Kimg + 8 * H3_ARR + o) = k3;
+            }
         }
         __syncthreads();
-        const int ci = ti * 32 + (lane & 31), cj = tj * 32 + (lane & 31);
-#pragma unroll 4
-        for (int kk = 0; kk < H3_PB / 2; ++kk) {
-            const int row = 2 * kk + (lane >> 5);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aa[row][ci], Bb[row][cj], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aa[row][63 - ci], Bc[row][cj], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[row][63 - ci], Bc[row][63 - cj], acc[2], 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < H3_PB / 16; ++s4) {
+            bf16x8 fa[3], fb[3];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                fa[part] = *(const bf16x8*)(Kimg + part * 4 * H3_ARR + koff(arow, abin, 2 * s4 + hk));
+                fb[part] = *(const bf16x8*)(Kimg + part * 4 * H3_ARR + koff(brow, bbin, 2 * s4 + hk));
+            }
+            // smallest partial products first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc, 0, 0, 0);
         }
-        __syncthreads();
     }
     float* out = part + ((long long)n * H3_PS + ps) * 3 * HB * HB;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            const int j = tj * 32 + (lane & 31);
-            out[(c * HB + i) * HB + j] = acc[c][e];
-        }
+    for (int e = 0; e < 16; ++e) {
+        const int i = ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+        const int j = tj * 32 + li;
+        out[(c * HB + i) * HB + j] = acc[e];
+    }
 }
 
 __global__ __launch_bounds__(256) void rgbuv_hist_fold_kernel(const float* __restrict__ part, float* __restrict__ hist) {
@@ -462,13 +510,6 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
 #define B3_NT 768
 #define B3_KIMG (3 * 3 * B3_PB * HB * 2)      // bytes of the split kernel-row image
 
-__device__ __forceinline__ void split3(float x, bf16_t& p1, bf16_t& p2, bf16_t& p3) {
-    p1 = (bf16_t)x;
-    const float r1 = x - (float)p1;
-    p2 = (bf16_t)r1;
-    p3 = (bf16_t)(r1 - (float)p2);
-}
-
 template <typename T>
 __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TView img, const float* __restrict__ gh,
                                                                float* __restrict__ dimg, int nsplit) {
@@ -665,8 +706,15 @@ extern "C" int p2p_rgbuv_hist_fwd3(int dtype, int N, int H, int W, const p2p_ten
     P2P_REQUIRE((points == nullptr) == (npoints == nullptr), "p2p_rgbuv_hist_fwd3: points and npoints come together");
     P2P_REQUIRE(((uintptr_t)workspace % 16) == 0 && ((uintptr_t)hist % 16) == 0, "p2p_rgbuv_hist_fwd3: alignment");
     hipStream_t st = (hipStream_t)stream;
-    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd3_kernel<T><<<dim3(N, H3_PS), 256, 0, st>>>(H, W, make_view(img), (const f32x4*)points,
-                                                                                        npoints, cap, workspace)));
+    constexpr int SHM = H3_KIMG + 4 * H3_PB * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)rgbuv_hist_fwd3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        (void)hipFuncSetAttribute((const void*)rgbuv_hist_fwd3_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        attr = true;
+    }
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd3_kernel<T><<<dim3(N, H3_PS), H3_NT, SHM, st>>>(H, W, make_view(img), (const f32x4*)points,
+                                                                                            npoints, cap, workspace)));
     int rc = p2p_check_launch("p2p_rgbuv_hist_fwd3");
     if (rc) return rc;
     rgbuv_hist_fold_kernel<<<dim3(N), 256, 0, st>>>(workspace, hist);
