@@ -537,6 +537,18 @@ static BrigPlan brig_plan(int op, int dtype, int N, int LH, int LW, int Cg, int 
     if (ncols % bn1 == 0 && (p.cbw == 0 || (fc != 2 && (long long)p.ntiles * (ncols / bn2) < 192))) p.cbw = 1;
     if (!p.cbw) return p;
     p.nnt = ncols / (p.cbw == 2 ? bn2 : bn1);
+    // A workgroup walks ALL of K alone (no split): with few pixel tiles the launch is a handful of long-running workgroups on an
+    // idle chip (r04: 2 workgroups and 40 us for the 8x8 layers at batch 4, 64 workgroups and 46 us at batch 128, where the
+    // pipelined im2col kernel with its K split takes 8-17 us).  Below P2P_BRIG_MIN_WG workgroups (default 160) the shape goes to
+    // p2p_igemm's im2col path (and the fused conv + InstanceNorm form is not offered).  The tests set 1 to reach this kernel with
+    // small batches.
+    {
+        const char* e = getenv("P2P_BRIG_MIN_WG");
+        const long long min_wg = e ? atoi(e) : 160;
+        // (launch-bound batches keep the fused block: at batch 4 the step is a chain of ~100 dependent launches and the extra
+        // normalisation launch of the im2col route costs more than the idle chip -- c1 0.935 vs 1.026 ms)
+        if (N >= 32 && (long long)p.ntiles * p.nnt < min_wg) return p;
+    }
     if (mode == 1) {
         p.BR = p.rpt + 2;
         p.PITCH = LW == 8 ? 12 : LW + 2;      // 8-wide maps: pitch 12 balances the pixel indices modulo 16 over the lane groups

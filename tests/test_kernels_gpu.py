@@ -605,6 +605,7 @@ def test_igemm_block_resident_wide_maps(op, n, lh, cg, cd, cbw, monkeypatch):
     if cbw == 2 and (cg if op == L.OP_P else cd) % (64 if op == L.OP_P else 256):
         pytest.skip("the 64-channels-per-wave form needs whole 64 / 256 channel tiles")
     monkeypatch.setenv("P2P_BRIG_CBW", str(cbw))
+    monkeypatch.setenv("P2P_BRIG_MIN_WG", "1")       # (the product keeps this kernel for launches that fill the chip)
     dtype = L.BF16
     assert L.lib().p2p_brig_ok(op, dtype, n, lh, lh, cg, cd) == 1
     rng = np.random.default_rng(23)
@@ -652,6 +653,7 @@ def test_fused_block_conv_instance_norm_activation(op, n, lh, cg, cd, act, cbw, 
     convolution result and the (mean, rstd) statistics equal convolution + p2p_norm_act_fwd in two launches and the oracle."""
     dtype = L.BF16
     monkeypatch.setenv("P2P_BRIG_CBW", str(cbw))
+    monkeypatch.setenv("P2P_BRIG_MIN_WG", "1")
     assert L.lib().p2p_igemm_norm_act_ok(op, dtype, n, lh, lh, cg, cd) == 1
     assert L.lib().p2p_igemm_norm_act_ok(L.OP_P, dtype, n, 32, 32, 64, 64) == 0        # strips of an image: not fusable
     rng = np.random.default_rng(29)
