@@ -112,8 +112,9 @@ __global__ __launch_bounds__(CS_THREADS) void conv_strip_kernel(CsArgs a) {
             const int p = tile * 32 + r;
             const int yy = p >> a.lgLW, x = p & (a.LW - 1);
             f32x16 acc;
+            const float zero = p2p_valu_zero();      // not the MFMA's "C = 0": the previous tile's stores may still be reading these registers
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[e] = zero;
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
                 int ry, rx;

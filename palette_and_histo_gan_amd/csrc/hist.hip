@@ -13,6 +13,7 @@
 // f32 slab [3][N*HW][4]; the consumer (p2p_tanh_l1_bwd) sums the slabs on load.
 #include "p2p_common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 #define HB 64                 // histogram size (histogram.py:36)
 #define HIST_EPS 1e-6f        // histogram.py:53
@@ -189,14 +190,20 @@ __global__ __launch_bounds__(256) void rgbuv_points_kernel(int H, int W, TView i
 // pixel counts) -- and writes one partial [3][64][64]; rgbuv_hist_fold_kernel adds the ranges in order.
 // Round 4: the contraction runs on the bf16 matrix pipe by three-way operand splitting (see rgbuv_hist_bwd3_kernel: x = x1 + x2 + x3
 // in bf16 parts, six partial products, f32 accumulate) instead of v_mfma_f32_32x32x2_f32 (f32 vector rate).  Twelve waves =
-// (component, row tile, column tile), one 32x32 accumulator each; the four operand arrays Iy ka, Iy kb (rows) and kb, kc (columns)
-// live in LDS as [part][array][bin][pixel] bf16 -- the contraction index (pixel) contiguous, 16-byte chunks XOR-swizzled by the bin --
-// so a mirrored bin index (63 - i) is just another row address.
+// (component, row tile, column tile), one 32x32 accumulator each.  The weight Iy enters as sqrt(Iy) on BOTH factors -- Iy ka[i] kb[j]
+// = (s ka[i]) (s kb[j]), s = sqrt(Iy): three operand arrays s ka, s kb, s kc serve all three products (with Iy on one factor the
+// three products need four arrays: one row kind both weighted and unweighted); each term differs from the reference's
+// (Iy ka) kb by two more f32 roundings.  The arrays live in LDS as [part][row][bin][pixel] bf16 -- the contraction index (pixel)
+// contiguous, 16-byte chunks XOR-swizzled by the bin -- so a mirrored bin index (63 - i) is just another row address.
+#ifndef P2P_HIST_ABL
+#define P2P_HIST_ABL 0        // tools/ubench: 1 no matrix products, 2 no kernel-row evaluation, 3 a quarter of the pairing sums, 4 no single-wave work
+#endif
 #define H3_PB 64
 #define H3_PS 3
 #define H3_NT 768
 #define H3_ARR (HB * H3_PB * 2)               // bytes of one part of one array
-#define H3_KIMG (3 * 4 * H3_ARR)
+#define H3_KIMG (3 * 3 * H3_ARR)              // one operand image: [3 parts][3 rows][64 bins][64 pixels] bf16
+#define H3_SHM (2 * H3_KIMG + 2 * 4 * H3_PB * 4)
 
 __device__ __forceinline__ void split3(float x, bf16_t& p1, bf16_t& p2, bf16_t& p3) {
     p1 = (bf16_t)x;
@@ -205,13 +212,56 @@ __device__ __forceinline__ void split3(float x, bf16_t& p1, bf16_t& p2, bf16_t& 
     p3 = (bf16_t)(r1 - (float)p2);
 }
 
+// The same split for two values at a time, on packed instructions (v_cvt_pk_bf16_f32, v_pk_add_f32): the kernel-row evaluation is
+// vector-ALU work of the same order as the matrix work it feeds, so its instruction count is the kernels' running time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(f32x2 x) { return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v)); }
+__device__ __forceinline__ f32x2 unpack_bf16x2(unsigned u) {
+    f32x2 r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+    return r;
+}
+#ifndef P2P_HIST_PK
+#define P2P_HIST_PK 1         // 1: two-value arithmetic on v_pk_*_f32; 0: plain instructions, value by value.  Measured equal within 2 % (a packed
+#endif                        // f32 instruction takes the issue time of two plain ones: tools/ubench/clock_probe.hip); 1 is the smaller code
+#if P2P_HIST_PK
+__device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b) { return a - b; }
+__device__ __forceinline__ f32x2 add2(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 mul2(f32x2 a, f32x2 b) { return a * b; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+// value by value; the empty asm keeps the two lanes' instructions from being re-packed
+__device__ __forceinline__ float keep1(float x) { asm("" : "+v"(x)); return x; }
+__device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b) { f32x2 r = {keep1(a.x - b.x), keep1(a.y - b.y)}; return r; }
+__device__ __forceinline__ f32x2 add2(f32x2 a, f32x2 b) { f32x2 r = {keep1(a.x + b.x), keep1(a.y + b.y)}; return r; }
+__device__ __forceinline__ f32x2 mul2(f32x2 a, f32x2 b) { f32x2 r = {keep1(a.x * b.x), keep1(a.y * b.y)}; return r; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { f32x2 r = {keep1(fmaf(a.x, b.x, c.x)), keep1(fmaf(a.y, b.y, c.y))}; return r; }
+#endif
+__device__ __forceinline__ void split3x2(f32x2 x, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pack_bf16x2(x);
+    const f32x2 r1 = sub2(x, unpack_bf16x2(p1));
+    p2 = pack_bf16x2(r1);
+    p3 = pack_bf16x2(sub2(r1, unpack_bf16x2(p2)));
+}
+// inverse-quadratic kernel of two coordinates (iq_kernel, same operation order)
+__device__ __forceinline__ f32x2 iq_kernel2(f32x2 t) {
+    const f32x2 inv = {INV_SIGMA2, INV_SIGMA2}, one = {1.0f, 1.0f};
+    const f32x2 q = fma2(mul2(t, t), inv, one);
+    f32x2 k = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+    return k;
+}
+
+// One barrier per batch of 64 pixels (see rgbuv_hist_bwd3_kernel for the measurement behind it): the operand image is double-
+// buffered, batch b's matrix products share an instruction stream with batch b+1's kernel-row evaluation, and waves 8-10 take the
+// per-pixel logs of batch b+2 (one row a, b, c each) along the way.
 template <typename T>
 __global__ __launch_bounds__(H3_NT) void rgbuv_hist_fwd3_kernel(int H, int W, TView img, const f32x4* __restrict__ points,
                                                                const int* __restrict__ npoints, int cap, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char h3_smem[];
-    char* const Kimg = h3_smem;                             // [3 parts][4 arrays: Iy ka, Iy kb, kb, kc][64 bins][64 pixels] bf16
-    float* const sa = (float*)(h3_smem + H3_KIMG);
-    float* const sb = sa + H3_PB; float* const sc = sb + H3_PB; float* const siy = sc + H3_PB;
+    char* const Kimg = h3_smem;                             // 2 x [3 parts][3 rows: s ka, s kb, s kc; s = sqrt(Iy)][64 bins][64 pixels] bf16
+    float* const slots = (float*)(h3_smem + 2 * H3_KIMG);   // 2 x {a, b, c, s}[64]: batch b lives in slot b & 1
     const int n = blockIdx.x, ps = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,71 +273,92 @@ __global__ __launch_bounds__(H3_NT) void rgbuv_hist_fwd3_kernel(int H, int W, TV
     int chunk = (total + H3_PS - 1) / H3_PS;
     chunk = (chunk + H3_PB - 1) / H3_PB * H3_PB;
     const int q0 = ps * chunk, q1 = min(total, q0 + chunk);
+    const int nb = (q1 - q0 + H3_PB - 1) / H3_PB;            // <= 0: this range is empty, the partial is zero
     // byte offset of (array, bin, 16-byte chunk of 8 pixels) inside one part
     auto koff = [](int arr, int bin, int ch) { return arr * H3_ARR + bin * (H3_PB * 2) + ((ch ^ ((bin >> 1) & 7)) << 4); };
-    // component c: H_R = (Iy ka)[i] kb[j],  H_G = (Iy ka)[63-i] kc[j],  H_B = (Iy kb)[63-i] kc[63-j]
+    // component c: H_R = (s ka)[i] (s kb)[j],  H_G = (s ka)[63-i] (s kc)[j],  H_B = (s kb)[63-i] (s kc)[63-j]
     const int li = lane & 31, hk = lane >> 5;
     const int ci = ti * 32 + li, cj = tj * 32 + li;
     const int arow = c == 2 ? 1 : 0, abin = c == 0 ? ci : 63 - ci;
-    const int brow = c == 0 ? 2 : 3, bbin = c == 2 ? 63 - cj : cj;
+    const int brow = c == 0 ? 1 : 2, bbin = c == 2 ? 63 - cj : cj;
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int p0 = q0; p0 < q1; p0 += H3_PB) {
-        __syncthreads();                                    // the previous batch's fragments have been read
-        if (tid < H3_PB) {
-            const int p = p0 + tid;
-            float a = 0.f, b = 0.f, cc = 0.f, iy = 0.f;
-            if (p < q1) {
-                float x[3], wgt = 1.f;
-                if (listed) {
-                    const f32x4 e = points[(long long)n * cap + p];
-                    x[0] = e[0] * 0.5f + 0.5f; x[1] = e[1] * 0.5f + 0.5f; x[2] = e[2] * 0.5f + 0.5f;
-                    wgt = e[3];
-                } else {
-                    load_rgb01<T>(img, n, p, W, x);
-                }
-                iy = wgt * sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + HIST_EPS);
-                const float lr = logf(x[0] + HIST_EPS), lg = logf(x[1] + HIST_EPS), lb = logf(x[2] + HIST_EPS);
-                a = lr - lg; b = lr - lb; cc = lg - lb;
+
+    // per-pixel values of batch b: wave 8 -> a = lR - lG, wave 9 -> b = lR - lB, wave 10 -> c = lG - lB and the weight's square root
+    auto prep = [&](int b) {
+        const int k = wave - 8, p = q0 + b * H3_PB + lane;
+        float co = 0.f, s = 0.f;                             // s = 0 beyond the range: contributes nothing
+        if (p < q1) {
+            float x[3], wgt = 1.f;
+            if (listed) {
+                const f32x4 e = points[(long long)n * cap + p];
+                x[0] = e[0] * 0.5f + 0.5f; x[1] = e[1] * 0.5f + 0.5f; x[2] = e[2] * 0.5f + 0.5f;
+                wgt = e[3];
+            } else {
+                load_rgb01<T>(img, n, p, W, x);
             }
-            sa[tid] = a; sb[tid] = b; sc[tid] = cc; siy[tid] = iy;       // iy = 0 beyond the range: contributes nothing
+            const float xi = k == 2 ? x[1] : x[0], xj = k == 0 ? x[1] : x[2];
+            co = logf(xi + HIST_EPS) - logf(xj + HIST_EPS);
+            s = sqrtf(wgt * sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + HIST_EPS));
         }
-        __syncthreads();
-        // one item = (row type a / b / c, bin, chunk of 8 pixels): evaluate the kernel row, split, store
-        for (int idx = tid; idx < 3 * HB * (H3_PB / 8); idx += H3_NT) {
-            const int rty = idx >> 9, bin = (idx >> 3) & 63, ch = idx & 7;
-            const float d = hist_center(bin);
-            const float* co = rty == 0 ? sa : (rty == 1 ? sb : sc);
-            bf16x8 w1, w2, w3, k1, k2, k3;
+        float* sl = slots + (b & 1) * (4 * H3_PB);
+        sl[k * H3_PB + lane] = co;
+        if (k == 2) sl[3 * H3_PB + lane] = s;
+    };
+    // kernel-row evaluation: item = (row a / b / c, bin, chunk of 8 pixels) = tid + 768 it, it = 0, 1; the chunk is the thread's own
+    const int ebin = (tid >> 3) & 63;
+    auto eval_load = [&](const float* sl, int it, f32x2 (&cs)[4], f32x2 (&ws)[4], float& d) {
+        const int rty = (tid + H3_NT * it) >> 9, bin = (ebin + 32 * it) & 63;
+        d = hist_center(bin);
+        const f32x4* co = (const f32x4*)(sl + rty * H3_PB + (tid & 7) * 8);
+        const f32x4* sw = (const f32x4*)(sl + 3 * H3_PB + (tid & 7) * 8);
+        const f32x4 c0 = co[0], c1 = co[1], w0 = sw[0], w1 = sw[1];
+        cs[0].x = c0[0]; cs[0].y = c0[1]; cs[1].x = c0[2]; cs[1].y = c0[3]; cs[2].x = c1[0]; cs[2].y = c1[1]; cs[3].x = c1[2]; cs[3].y = c1[3];
+        ws[0].x = w0[0]; ws[0].y = w0[1]; ws[1].x = w0[2]; ws[1].y = w0[3]; ws[2].x = w1[0]; ws[2].y = w1[1]; ws[3].x = w1[2]; ws[3].y = w1[3];
+    };
+    auto eval_pairs = [&](const f32x2 (&cs)[4], const f32x2 (&ws)[4], float d, int half, u32x4& k1, u32x4& k2, u32x4& k3) {
+        const f32x2 d2 = {d, d};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int p = ch * 8 + e;
-                const float k = iq_kernel(co[p] - d);
-                bf16_t q1b, q2b, q3b;
-                split3(k, q1b, q2b, q3b);
-                k1[e] = q1b; k2[e] = q2b; k3[e] = q3b;
-                split3(siy[p] * k, q1b, q2b, q3b);
-                w1[e] = q1b; w2[e] = q2b; w3[e] = q3b;
-            }
-            if (rty <= 1) {                   // Iy ka -> array 0, Iy kb -> array 1
-                const int o = koff(rty, bin, ch);
-                *(bf16x8*)(Kimg + o) = w1; *(bf16x8*)(Kimg + 4 * H3_ARR + o) = w2; *(bf16x8*)(Kimg + 8 * H3_ARR + o) = w3;
-            }
-            if (rty >= 1) {                   // kb -> array 2, kc -> array 3
-                const int o = koff(rty + 1, bin, ch);
-                *(bf16x8*)(Kimg + o) = k1; *(bf16x8*)(Kimg + 4 * H3_ARR + o) = k2; *(bf16x8*)(Kimg + 8 * H3_ARR + o) = k3;
-            }
+        for (int e2 = 2 * half; e2 < 2 * half + 2; ++e2) {
+            unsigned q1b, q2b, q3b;
+            split3x2(mul2(ws[e2], iq_kernel2(sub2(cs[e2], d2))), q1b, q2b, q3b);
+            k1[e2] = q1b; k2[e2] = q2b; k3[e2] = q3b;
         }
-        __syncthreads();
+    };
+    auto eval_store = [&](char* Kd, int it, const u32x4& k1, const u32x4& k2, const u32x4& k3) {
+        const int rty = (tid + H3_NT * it) >> 9, bin = (ebin + 32 * it) & 63;
+        const int o = koff(rty, bin, tid & 7);
+        *(u32x4*)(Kd + o) = k1; *(u32x4*)(Kd + 3 * H3_ARR + o) = k2; *(u32x4*)(Kd + 6 * H3_ARR + o) = k3;
+    };
+    auto batch = [&](int b, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const char* const Kc = Kimg + (b & 1) * H3_KIMG;
+        char* const Kn = Kimg + ((b + 1) & 1) * H3_KIMG;
+        const float* const sln = slots + ((b + 1) & 1) * (4 * H3_PB);
+        if (wave >= 8 && wave < 11 && b + 2 < nb) prep(b + 2);
+        f32x2 cs[4], ws[4];
+        float d = 0.f;
+        u32x4 k1, k2, k3;
 #pragma unroll
         for (int s4 = 0; s4 < H3_PB / 16; ++s4) {
             bf16x8 fa[3], fb[3];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                fa[part] = *(const bf16x8*)(Kimg + part * 4 * H3_ARR + koff(arow, abin, 2 * s4 + hk));
-                fb[part] = *(const bf16x8*)(Kimg + part * 4 * H3_ARR + koff(brow, bbin, 2 * s4 + hk));
+                fa[part] = *(const bf16x8*)(Kc + part * 3 * H3_ARR + koff(arow, abin, 2 * s4 + hk));
+                fb[part] = *(const bf16x8*)(Kc + part * 3 * H3_ARR + koff(brow, bbin, 2 * s4 + hk));
             }
+            if (MORE && P2P_HIST_ABL != 2) {
+                if ((s4 & 1) == 0) eval_load(sln, s4 >> 1, cs, ws, d);
+                eval_pairs(cs, ws, d, s4 & 1, k1, k2, k3);
+            }
+#if P2P_HIST_ABL == 1
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                acc[0] += __uint_as_float((__builtin_bit_cast(u32x4, fa[part])[0] ^ __builtin_bit_cast(u32x4, fb[part])[3]) & 0x7fffffu);
+            if (MORE && (s4 & 1) == 1) eval_store(Kn, s4 >> 1, k1, k2, k3);
+            continue;
+#endif
             // smallest partial products first
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc, 0, 0, 0);
@@ -295,7 +366,27 @@ __global__ __launch_bounds__(H3_NT) void rgbuv_hist_fwd3_kernel(int H, int W, TV
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc, 0, 0, 0);
+            if (MORE && P2P_HIST_ABL != 2 && (s4 & 1) == 1) eval_store(Kn, s4 >> 1, k1, k2, k3);
         }
+        __syncthreads();
+    };
+    if (nb > 0) {
+        // prologue: per-pixel values of batches 0 and 1, operand image of batch 0
+        if (wave >= 8 && wave < 11) { prep(0); if (nb > 1) prep(1); }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x2 cs[4], ws[4];
+            float d;
+            u32x4 k1, k2, k3;
+            eval_load(slots, it, cs, ws, d);
+            eval_pairs(cs, ws, d, 0, k1, k2, k3);
+            eval_pairs(cs, ws, d, 1, k1, k2, k3);
+            eval_store(Kimg, it, k1, k2, k3);
+        }
+        __syncthreads();
+        for (int b = 0; b < nb - 1; ++b) batch(b, std::true_type{});
+        batch(nb - 1, std::false_type{});
     }
     float* out = part + ((long long)n * H3_PS + ps) * 3 * HB * HB;
 #pragma unroll
@@ -508,18 +599,24 @@ __global__ __launch_bounds__(256) void rgbuv_hist_bwd_kernel(int H, int W, TView
 // the kernel rows from LDS: [part][row][pixel][bin] bf16, 16-byte chunks XOR-swizzled by the pixel (conflict-free ds_read_b128).
 #define B3_PB 64
 #define B3_NT 768
-#define B3_KIMG (3 * 3 * B3_PB * HB * 2)      // bytes of the split kernel-row image
+#define B3_KBUF (3 * 3 * B3_PB * HB * 2)      // bytes of one split kernel-row image: [3 parts][3 rows][64 pixels][64 bins] bf16
+#define B3_SLOT (6 * B3_PB)                   // floats of one batch's per-pixel values: log x [3][64], x [3][64]
+#define B3_RACC (18 * B3_PB)                  // floats of one batch's partial sums: [3 comps][2 row tiles][diy | du | dv][pixel]
+#define B3_SHM (2 * B3_KBUF + (4 * B3_SLOT + 2 * B3_RACC) * 4)
 
+// Round 4, second half: ONE barrier per batch of 64 pixels.  Measured on the five-phase form (per-pixel logs by one wave | kernel rows
+// | matrix products | pairing sums | per-pixel result by one wave, a barrier between each): the matrix pipe holds a third of the
+// batch time, vector work a third, and the two single-wave phases with their barriers the rest.  Now the kernel-row image is double-
+// buffered and batch b's matrix products run in the same instruction stream as batch b+1's kernel-row evaluation (no dependence:
+// the vector instructions issue under the 8-pass MFMAs), the per-pixel logs of batch b+2 (waves 8-10, one colour channel each) and
+// the per-pixel result of batch b-1 (wave 11) ride along on single waves, and the only barrier closes the batch.
 template <typename T>
 __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TView img, const float* __restrict__ gh,
                                                                float* __restrict__ dimg, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) char b3_smem[];
-    char* const Kimg = b3_smem;                                                      // [3 parts][3 rows a, b, c][64 pixels][64 bins] bf16
-    float* fl = (float*)(b3_smem + B3_KIMG);
-    float (*sco)[B3_PB] = (float (*)[B3_PB])fl;               // [3] a, b, c
-    float* siy = fl + 3 * B3_PB;
-    float (*sx)[4] = (float (*)[4])(siy + B3_PB);             // [PB][4]
-    float (*racc)[2][3][B3_PB] = (float (*)[2][3][B3_PB])(siy + B3_PB + 4 * B3_PB);   // [3 comps][2 row tiles][diy | du | dv][pixel]
+    char* const Kimg = b3_smem;                                                      // 2 x [3 parts][3 rows a, b, c][64 pixels][64 bins] bf16
+    float* const slots = (float*)(b3_smem + 2 * B3_KBUF);                             // 4 x {log x [3][64], x [3][64]}: batch b lives in slot b & 3
+    float* const raccs = slots + 4 * B3_SLOT;                                         // 2 x [3 comps][2 row tiles][3][64]: batch b in b & 1
     const int n = blockIdx.x, ps = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -527,14 +624,18 @@ __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TV
     int chunk = (HW + nsplit - 1) / nsplit;
     chunk = (chunk + B3_PB - 1) / B3_PB * B3_PB;
     const int q0 = ps * chunk, q1 = min(HW, q0 + chunk);
+    const int nb = (q1 - q0 + B3_PB - 1) / B3_PB;
+    if (nb <= 0) return;
     const int c = wave >> 2, prod = (wave >> 1) & 1, rt = wave & 1;
     // (u, v) of component c in terms of the shared rows: row index, mirrored?
     const int ua = c == 2 ? 1 : 0, va = c == 0 ? 1 : 2;
     const bool um = c != 0, vm = c == 2;
     const int ra = prod == 0 ? va : ua, oa = prod == 0 ? ua : va;          // contracted rows / the rows the result is paired with
     const bool om = prod == 0 ? um : vm;
-    const float osign = om ? -1.f : 1.f;
+    const float osign = __int_as_float(__builtin_amdgcn_readfirstlane(om ? 0xbf800000 : 0x3f800000));      // wave-uniform: a scalar register
     const int li = lane & 31, hk = lane >> 5;
+    // row r = log x[ri] - log x[rj]:  a = lR - lG, b = lR - lB, c = lG - lB
+    const int oi = oa == 2 ? 1 : 0, oj = oa == 0 ? 1 : 2;
 
     // ---- this wave's slice of the gradient matrix as A fragments: GH'[i'][j'] = GH_c[um ? 63 - i' : i'][vm ? 63 - j' : j'];
     // product 0: A[row][k] = GH'[rt*32 + row][k],  product 1: A[row][k] = GH'[k][rt*32 + row]   (lane: row = li, k = 16 s + 8 hk + e)
@@ -557,52 +658,106 @@ __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TV
     // byte offset of (row, pixel, 16-byte chunk) inside one part of the kernel-row image
     auto koff = [](int row, int p, int ch) { return (row * B3_PB + p) * (HB * 2) + ((ch ^ ((p >> 1) & 7)) << 4); };
     constexpr int KPART = 3 * B3_PB * HB * 2;
-    for (int p0 = q0; p0 < q1; p0 += B3_PB) {
-        __syncthreads();
-        if (tid < B3_PB) {
-            const int p = p0 + tid;
-            float a = 0.f, b = 0.f, cc = 0.f, iy = 1.f, x[3] = {1.f, 1.f, 1.f};
-            if (p < q1) {
-                load_rgb01<T>(img, n, p, W, x);
-                iy = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + HIST_EPS);
-                const float lr = logf(x[0] + HIST_EPS), lg = logf(x[1] + HIST_EPS), lb = logf(x[2] + HIST_EPS);
-                a = lr - lg; b = lr - lb; cc = lg - lb;
-            }
-            sco[0][tid] = a; sco[1][tid] = b; sco[2][tid] = cc; siy[tid] = iy;
-            sx[tid][0] = x[0]; sx[tid][1] = x[1]; sx[tid][2] = x[2];
-        }
-        __syncthreads();
-        // kernel rows, split: one 16-byte chunk (8 bins of one pixel) of each part per item
-        for (int idx = tid; idx < 3 * B3_PB * 8; idx += B3_NT) {
-            const int r = idx >> 9, p = (idx >> 3) & 63, ch = idx & 7;
-            const float co = sco[r][p];
-            bf16x8 k1, k2, k3;
+    // kernel-row evaluation: item = (row, pixel, chunk of 8 bins) = tid + 768 it, it = 0, 1; the chunk is the thread's own (768 = 0
+    // mod 8): its eight bin centres stay in registers
+    f32x2 cen2[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                bf16_t q1b, q2b, q3b;
-                split3(iq_kernel(co - hist_center(ch * 8 + e)), q1b, q2b, q3b);
-                k1[e] = q1b; k2[e] = q2b; k3[e] = q3b;
-            }
-            const int o = koff(r, p, ch);
-            *(bf16x8*)(Kimg + o) = k1;
-            *(bf16x8*)(Kimg + KPART + o) = k2;
-            *(bf16x8*)(Kimg + 2 * KPART + o) = k3;
+    for (int e2 = 0; e2 < 4; ++e2) { cen2[e2].x = hist_center((tid & 7) * 8 + 2 * e2); cen2[e2].y = hist_center((tid & 7) * 8 + 2 * e2 + 1); }
+    const int ep = (tid >> 3) & 63;                                         // the items' pixel (768 / 8 = 96 = 32 mod 64: + 32 for it = 1)
+    auto eval_coord = [&](const float* sl, int it) {
+        const int r = (tid + B3_NT * it) >> 9, p = (ep + 32 * it) & 63;     // r: 0 0 0 0 0 0 0 0 1 1 1 1 | 1 1 1 1 2 2 2 2 2 2 2 2 by wave
+        const int ri = r == 2 ? 1 : 0, rj = r == 0 ? 1 : 2;
+        return sl[ri * B3_PB + p] - sl[rj * B3_PB + p];
+    };
+    auto eval_pairs = [&](float co, int half, u32x4& k1, u32x4& k2, u32x4& k3) {
+        const f32x2 co2 = {co, co};
+#pragma unroll
+        for (int e2 = 2 * half; e2 < 2 * half + 2; ++e2) {
+            unsigned q1b, q2b, q3b;
+            split3x2(iq_kernel2(sub2(co2, cen2[e2])), q1b, q2b, q3b);
+            k1[e2] = q1b; k2[e2] = q2b; k3[e2] = q3b;
         }
-        __syncthreads();
+    };
+    auto eval_store = [&](char* Kd, int it, const u32x4& k1, const u32x4& k2, const u32x4& k3) {
+        const int r = (tid + B3_NT * it) >> 9, p = (ep + 32 * it) & 63;
+        const int o = koff(r, p, tid & 7);
+        *(u32x4*)(Kd + o) = k1;
+        *(u32x4*)(Kd + KPART + o) = k2;
+        *(u32x4*)(Kd + 2 * KPART + o) = k3;
+    };
+    // per-pixel logs of batch b: waves 8, 9, 10 take one colour channel each
+    auto prep = [&](int b) {
+        const int k = wave - 8, p = q0 + b * B3_PB + lane;
+        float x[3] = {1.f, 1.f, 1.f};
+        if (p < q1) load_rgb01<T>(img, n, p, W, x);
+        const float xk = k == 0 ? x[0] : (k == 1 ? x[1] : x[2]);
+        float* sl = slots + (b & 3) * B3_SLOT;
+        sl[k * B3_PB + lane] = logf(xk + HIST_EPS);
+        sl[(3 + k) * B3_PB + lane] = xk;
+    };
+    // per-pixel result of batch b (wave 11): the twelve waves' partial sums -> d img
+    auto finish = [&](int b) {
+        const int p = q0 + b * B3_PB + lane;
+        if (p >= q1) return;
+        const float* sl = slots + (b & 3) * B3_SLOT;
+        const float (*racc)[2][3][B3_PB] = (const float (*)[2][3][B3_PB])(raccs + (b & 1) * B3_RACC);
+        float diy = 0.f, du[3], dv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            diy += racc[k][0][0][lane] + racc[k][1][0][lane];
+            du[k] = racc[k][0][1][lane] + racc[k][1][1][lane];
+            dv[k] = racc[k][0][2][lane] + racc[k][1][2][lane];
+        }
+        // u0 = lR - lG, v0 = lR - lB;  u1 = lG - lR, v1 = lG - lB;  u2 = lB - lR, v2 = lB - lG    (histogram.py:72-74)
+        const float dl[3] = {(du[0] + dv[0]) - du[1] - du[2], (du[1] + dv[1]) - du[0] - dv[2], (du[2] + dv[2]) - dv[0] - dv[1]};
+        const float x0 = sl[3 * B3_PB + lane], x1 = sl[4 * B3_PB + lane], x2 = sl[5 * B3_PB + lane];
+        const float xs[3] = {x0, x1, x2};
+        const float iy = sqrtf(x0 * x0 + x1 * x1 + x2 * x2 + HIST_EPS);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = 0.5f * (iy * dl[k] / (xs[k] + HIST_EPS) + diy * xs[k] / iy);      // x = img * 0.5 + 0.5; du, dv carry Iy
+        o[3] = 0.f;                                                                                          // alpha has no gradient
+        *(f32x4*)(dimg + ((long long)n * HW + p) * 4) = o;
+    };
+
+    // ---- one batch: [result of b-1 | logs of b+2] on single waves; products of b with the kernel rows of b+1 in their shadow;
+    // pairing sums of b; barrier
+    auto batch = [&](int b, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        char* const Kc = Kimg + (b & 1) * B3_KBUF;
+        char* const Kn = Kimg + ((b + 1) & 1) * B3_KBUF;
+        const float* const slc = slots + (b & 3) * B3_SLOT;
+        const float* const sln = slots + ((b + 1) & 3) * B3_SLOT;
+#if P2P_HIST_ABL != 4
+        if (wave >= 8 && wave < 11 && b + 2 < nb) prep(b + 2);
+#endif
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        u32x4 k1, k2, k3;
+        float co = 0.f;
+        int kb_keep = 0; (void)kb_keep;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             bf16x8 kb[3][2];                                  // B fragments: [part][pixel tile]: pixel = t*32 + li, bins 16 s + 8 hk ..
 #pragma unroll
             for (int part = 0; part < 3; ++part)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) kb[part][t] = *(const bf16x8*)(Kimg + part * KPART + koff(ra, t * 32 + li, 2 * s4 + hk));
+                for (int t = 0; t < 2; ++t) kb[part][t] = *(const bf16x8*)(Kc + part * KPART + koff(ra, t * 32 + li, 2 * s4 + hk));
+            if (MORE && P2P_HIST_ABL != 2) {
+                if ((s4 & 1) == 0) co = eval_coord(sln, s4 >> 1);
+                eval_pairs(co, s4 & 1, k1, k2, k3);
+            }
+#if P2P_HIST_ABL == 1
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) kb_keep ^= __builtin_bit_cast(u32x4, kb[part][t])[0] ^ __builtin_bit_cast(u32x4, kb[part][t])[3];
+#endif
+#pragma unroll
+            for (int t = 0; t < 2 && P2P_HIST_ABL != 1; ++t) {
                 // smallest partial products first
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1][s4], kb[1][t], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2][s4], kb[0][t], acc[t], 0, 0, 0);
@@ -611,57 +766,73 @@ __global__ __launch_bounds__(B3_NT) void rgbuv_hist_bwd3_kernel(int H, int W, TV
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0][s4], kb[1][t], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0][s4], kb[0][t], acc[t], 0, 0, 0);
             }
+            if (MORE && P2P_HIST_ABL != 2 && (s4 & 1) == 1) eval_store(Kn, s4 >> 1, k1, k2, k3);
         }
+#if P2P_HIST_ABL == 1
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][0] = __int_as_float(kb_keep);
+#endif
+        // The result of batch b-1 goes out AFTER this batch's last MFMA and is waited for before the barrier: an MFMA's write-back is
+        // not interlocked against a pending global store's read of its data registers (measured, tools/exp/hist_repro.py: with the
+        // store ahead of the batch's first MFMA, whose result registers happened to be the store's data registers, one workgroup in
+        // a thousand stored a wrong first dword for its last 16 lanes; vector-instruction and LDS-return writes ARE interlocked).
+#if P2P_HIST_ABL != 4
+        if (wave == 11 && b > 0) finish(b - 1);
+#endif
+        float (*racc)[2][3][B3_PB] = (float (*)[2][3][B3_PB])(raccs + (b & 1) * B3_RACC);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pcol = j * 32 + li;
-            const float cval = sco[oa][pcol] - cen0;     // a, b or c at the lane's pixel minus the first row's centre (the mirror is the sign `osign`)
-            float s0 = 0.f, s1 = 0.f;                    // sum D k,  sum D k^2 (coord - d)
-            typedef __attribute__((__vector_size__(4 * sizeof(bf16_t)))) bf16_t bf16x4;
+            // a, b or c at the lane's pixel minus the first row's centre (the mirror is the sign `osign`)
+            const float cval = (slc[oi * B3_PB + pcol] - slc[oj * B3_PB + pcol]) - cen0;
+            f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};      // sum D k,  sum D k^2 (coord - d), two rows at a time (packed f32 instructions)
+            const f32x2 cv2 = {cval, cval};
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
+            for (int g4 = 0; g4 < (P2P_HIST_ABL == 3 ? 1 : 4); ++g4) {
                 // rows rt*32 + 8 g4 + 4 hk + 0..3 = bins of chunk rt*4 + g4, second half for hk = 1
                 const int o = koff(oa, pcol, rt * 4 + g4) + 8 * hk;
-                const bf16x4 v1 = *(const bf16x4*)(Kimg + o), v2 = *(const bf16x4*)(Kimg + KPART + o), v3 = *(const bf16x4*)(Kimg + 2 * KPART + o);
+                const u32x2 v1 = *(const u32x2*)(Kc + o), v2 = *(const u32x2*)(Kc + KPART + o), v3 = *(const u32x2*)(Kc + 2 * KPART + o);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = 4 * g4 + k;
-                    const float kq = ((float)v1[k] + (float)v2[k]) + (float)v3[k];
-                    const float w = acc[j][e] * kq;
-                    s0 += w;
-                    s1 = fmaf(w * kq, cval - (float)((e & 3) + 8 * (e >> 2)) * (6.0f / 63.0f), s1);
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 4 * g4 + 2 * h;
+                    const f32x2 kq = add2(add2(unpack_bf16x2(v1[h]), unpack_bf16x2(v2[h])), unpack_bf16x2(v3[h]));
+                    const f32x2 d2 = {acc[j][e], acc[j][e + 1]};
+                    const f32x2 w = mul2(d2, kq);
+                    const f32x2 off = {(float)((e & 3) + 8 * (e >> 2)) * (6.0f / 63.0f), (float)(((e + 1) & 3) + 8 * ((e + 1) >> 2)) * (6.0f / 63.0f)};
+                    t0 = add2(t0, w);
+                    t1 = fma2(mul2(w, kq), sub2(cv2, off), t1);
                 }
             }
+            float s0 = t0.x + t0.y, s1 = t1.x + t1.y;
             s0 += __shfl_xor(s0, 32, 64);
             s1 += __shfl_xor(s1, 32, 64);
             if (hk == 0) {
-                // sum_rows D g(t) k^2 with g(t) = -2 (coord - d) / sigma^2, coord - d = osign (shared coordinate - mirrored centre)
-                const float part1 = (-2.0f * INV_SIGMA2) * osign * s1 * siy[pcol];
+                // sum_rows D g(t) k^2 with g(t) = -2 (coord - d) / sigma^2, coord - d = osign (shared coordinate - mirrored centre);
+                // the factor Iy of du, dv is applied once, to their sum, by finish()
+                const float part1 = (-2.0f * INV_SIGMA2) * osign * s1;
                 if (prod == 0) { racc[c][rt][0][pcol] = s0; racc[c][rt][1][pcol] = part1; }
                 else { racc[c][rt][2][pcol] = part1; }
             }
         }
+        if (wave == 11) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): finish()'s store has left the registers the next batch's MFMAs write
         __syncthreads();
-        if (tid < B3_PB && p0 + tid < q1) {
-            float diy = 0.f, du[3], dv[3];
+    };
+
+    // ---- prologue: logs of batches 0 and 1, kernel rows of batch 0
+    if (wave >= 8 && wave < 11) { prep(0); if (nb > 1) prep(1); }
+    __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                diy += racc[k][0][0][tid] + racc[k][1][0][tid];
-                du[k] = racc[k][0][1][tid] + racc[k][1][1][tid];
-                dv[k] = racc[k][0][2][tid] + racc[k][1][2][tid];
-            }
-            // u0 = lR - lG, v0 = lR - lB;  u1 = lG - lR, v1 = lG - lB;  u2 = lB - lR, v2 = lB - lG    (histogram.py:72-74)
-            const float dl[3] = {(du[0] + dv[0]) - du[1] - du[2], (du[1] + dv[1]) - du[0] - dv[2], (du[2] + dv[2]) - dv[0] - dv[1]};
-            const float iy = siy[tid];
-            float* o = dimg + ((long long)n * HW + p0 + tid) * 4;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float xk = sx[tid][k];
-                o[k] = 0.5f * (dl[k] / (xk + HIST_EPS) + diy * xk / iy);          // x = img * 0.5 + 0.5
-            }
-            o[3] = 0.f;                                                           // alpha has no gradient
-        }
+    for (int it = 0; it < 2; ++it) {
+        u32x4 k1, k2, k3;
+        const float co = eval_coord(slots, it);
+        eval_pairs(co, 0, k1, k2, k3);
+        eval_pairs(co, 1, k1, k2, k3);
+        eval_store(Kimg, it, k1, k2, k3);
     }
+    __syncthreads();
+    for (int b = 0; b < nb - 1; ++b) batch(b, std::true_type{});
+    batch(nb - 1, std::false_type{});
+    if (wave == 11) finish(nb - 1);
 }
 
 // hist_out[n][i][j][c] = raw[n][c][i][j] / sum(raw[n])  -- the reference's normalised (B,64,64,3) tensor (histogram.py:75-79)
@@ -706,7 +877,7 @@ extern "C" int p2p_rgbuv_hist_fwd3(int dtype, int N, int H, int W, const p2p_ten
     P2P_REQUIRE((points == nullptr) == (npoints == nullptr), "p2p_rgbuv_hist_fwd3: points and npoints come together");
     P2P_REQUIRE(((uintptr_t)workspace % 16) == 0 && ((uintptr_t)hist % 16) == 0, "p2p_rgbuv_hist_fwd3: alignment");
     hipStream_t st = (hipStream_t)stream;
-    constexpr int SHM = H3_KIMG + 4 * H3_PB * 4;
+    constexpr int SHM = H3_SHM;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)rgbuv_hist_fwd3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
@@ -747,7 +918,8 @@ extern "C" int p2p_rgbuv_hist_hellinger_bwd3(int dtype, int N, int H, int W, con
     if (rc) return rc;
     int nsplit = 1;
     while (N * nsplit < 256 && (H * W) / (nsplit * 2) >= 8 * B3_PB) nsplit *= 2;       // one 12-wave workgroup per CU
-    constexpr int SHM = B3_KIMG + (3 * B3_PB + B3_PB + 4 * B3_PB + 18 * B3_PB) * 4;
+    constexpr int SHM = B3_SHM;
+    static_assert(SHM <= 160 * 1024, "rgbuv_hist_bwd3_kernel: LDS");
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)rgbuv_hist_bwd3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);

@@ -129,6 +129,17 @@ __device__ __forceinline__ void p2p_glds16_sv(const char* sbase, unsigned voff, 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// A zero that reaches an accumulator through VECTOR moves.  hipcc starts an accumulation with the first MFMA's "C = 0" form, whose
+// write-back can land in registers that a global store issued just before still has to read as its data: the matrix pipe's
+// write-back is not interlocked against that read (measured in round 4, tools/exp/hist_repro.py and tools/exp/store_mfma_hazard.py:
+// one workgroup in a thousand stored a wrong dword), a vector instruction's write is.  Kernels that store a tile and start the next
+// tile's MFMAs in the same wave zero their accumulators from this value.
+__device__ __forceinline__ float p2p_valu_zero() {
+    float z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
 __device__ __forceinline__ unsigned p2p_lds32(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }

@@ -150,6 +150,38 @@ def test_hellinger_loss_and_gradient_match_closed_form(size):
     assert np.linalg.norm(got3 - got) / np.linalg.norm(got) < 1e-4          # against the per-component form: f32 summation order only
 
 
+def test_histogram_gradient_kernel_is_reproducible_launch_to_launch():
+    """p2p_rgbuv_hist_hellinger_bwd3 stores each batch's result while the next batch's MFMAs are in flight.  Round 4 measured that an
+    MFMA's write-back is not interlocked against a pending global store's read of its data registers (a first version stored a wrong
+    dword in about one workgroup per thousand: tools/exp/hist_repro.py): the kernel now orders the two itself.  200 launches on one
+    input, four workgroups per image (16 batches each), must agree bit for bit."""
+    rng = np.random.default_rng(35)
+    B, size = 64, 64
+    _, tgt = rg.synthetic_rgba_batch(rng, 8, 64, palette_size=24)
+    tgt = np.tile(tgt, (B // 8, 1, 1, 1))
+    fake = np.clip(tgt + rng.normal(scale=0.05, size=tgt.shape), -1, 1).astype(np.float32)
+    t_d, f_d = U.dev(tgt), U.dev(fake)
+    vt, vf = L.Tensor(t_d.data_ptr(), size * size, size, 4), L.Tensor(f_d.data_ptr(), size * size, size, 4)
+    n = B * 3 * 64 * 64
+    h_r, h_f, gh = (torch.empty(n, dtype=torch.float32, device=U.DEV) for _ in range(3))
+    ws = torch.empty(L.lib().p2p_rgbuv_hist_fwd3_workspace_bytes(B) // 4, dtype=torch.float32, device=U.DEV)
+    tot = torch.empty((2, B), dtype=torch.float32, device=U.DEV)
+    sq, sqp = torch.zeros(4, dtype=torch.float32, device=U.DEV), torch.zeros(B, dtype=torch.float32, device=U.DEV)
+    for view, out in ((vt, h_r), (vf, h_f)):
+        L.call("p2p_rgbuv_hist_fwd3", L.F32, B, size, size, C.byref(view), None, None, 1024, U.ptr(out), U.ptr(ws), U.stream())
+    L.call("p2p_hellinger_fwd", U.ptr(h_r), U.ptr(h_f), B, U.ptr(tot[0]), U.ptr(tot[1]), U.ptr(sqp), U.ptr(sq), U.stream())
+    first = None
+    for i in range(200):
+        dimg = torch.full((B * size * size * 4,), float("nan"), dtype=torch.float32, device=U.DEV)
+        L.call("p2p_rgbuv_hist_hellinger_bwd3", L.F32, B, size, size, C.byref(vf), U.ptr(h_r), U.ptr(h_f), U.ptr(tot[0]), U.ptr(tot[1]),
+               U.ptr(sq), 1.0 / (2.0 * math.sqrt(2.0) * B), U.ptr(gh), U.ptr(dimg), U.stream())
+        if first is None:
+            first = dimg
+            assert bool(torch.isfinite(first).all())
+        else:
+            assert bool((dimg == first).all()), f"launch {i} differs from launch 0"
+
+
 def test_histogram_model_train_step_matches_oracle():
     B, S = 2, 64
     rng, Gp, Dp, src, tgt, masks = setup_case(B, S, 34)
