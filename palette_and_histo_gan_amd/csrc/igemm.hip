@@ -411,6 +411,10 @@ template <typename F> __device__ __forceinline__ void lds_read16(F& d, unsigned 
     static_assert(sizeof(F) == 16, "one ds_read_b128");
     asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr));
 }
+template <int OFF, typename F> __device__ __forceinline__ void lds_read16_off(F& d, unsigned addr) {
+    static_assert(sizeof(F) == 16 && OFF >= 0 && OFF < 65536, "one ds_read_b128 with an immediate offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
 template <int N> __device__ __forceinline__ void lgkm_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);      // register-only MFMAs must not be hoisted above the wait (cdna_hip_programming.md rule 18)
@@ -482,17 +486,22 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
         s_ak = in_lo + (dy * rowB + dx * pixB + cb0);
         s_wk = a.w + ((long long)widx * wtap + cb0);
     };
+    // LDS image: the ring's stages are interleaved at the granularity of one LDS-DMA piece (8 rows x 128 B = 1 KiB): piece q of stage
+    // st lies at (q * NST + st) * 1024, A pieces first.  A fragment row's address is then the same register for every stage and
+    // the stage is an immediate offset of the ds_read (st * 1024 < 64 K): the K loop, unrolled over the ring, carries no vector
+    // address arithmetic (r04: 8 v_add_u32 per 8 MFMAs before; vector and matrix instructions of a SIMD do not overlap --
+    // tools/ubench/clock_probe.hip).  Bank behaviour is that of the flat image: address bits 0..9 are unchanged.
+    constexpr int A_ALL = NST * A_BYTES;
     const unsigned smem32 = p2p_lds32(smem);
-    auto stage_piece = [&](char* buf, auto pc) {          // piece p (0 .. NL-1) of this wave
+    auto stage_piece = [&](int st, auto pc) {             // piece p (0 .. NL-1) of this wave, into ring slot st
         constexpr int p = decltype(pc)::value;
         if (P2P_ABL == 2) return;
-        const unsigned dst = smem32 + (unsigned)(buf - smem);
-        if constexpr (p < NA) p2p_glds16_sv(s_ak, abq[p], dst + (p * NW + wave) * 1024);
-        else p2p_glds16_sv(s_wk, bbq[p - NA], dst + A_BYTES + ((p - NA) * NW + wave) * 1024);
+        if constexpr (p < NA) p2p_glds16_sv(s_ak, abq[p], smem32 + (((p * NW + wave) * NST + st) << 10));
+        else p2p_glds16_sv(s_wk, bbq[p - NA], smem32 + A_ALL + ((((p - NA) * NW + wave) * NST + st) << 10));
     };
-    auto stage_all = [&](int kb, char* buf) {
+    auto stage_all = [&](int kb, int st) {
         stage_prepare(kb);
-        igemm_static_for(std::make_integer_sequence<int, NL>{}, [&](auto pc) { stage_piece(buf, pc); });
+        igemm_static_for(std::make_integer_sequence<int, NL>{}, [&](auto pc) { stage_piece(st, pc); });
     };
     // all but the `n` youngest stages of LDS-DMA have landed (n wave-uniform, 0 .. NST - 2)
     auto vm_wait_stages = [&](int n) {
@@ -509,8 +518,8 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // fragment read addresses inside a stage: row * 128 + ((2s + h) ^ swizzle(row)) * 16 = (row * 128 + ((h ^ swizzle) << 4)) ^ (s << 5);
-    // K group kg takes the k-steps s = KS * kg .. KS * kg + KS - 1 of every K-block
+    // fragment read addresses inside ring slot 0: piece(row) * NST KiB + (row & 7) * 128 + ((2s + h) ^ swizzle(row)) * 16, the last two terms
+    // = ((row & 7) * 128 + ((h ^ swizzle) << 4)) ^ (s << 5);  K group kg takes the k-steps s = KS * kg .. KS * kg + KS - 1 of every K-block
     typedef typename Frag<T>::type frag_t;
     const int h = lane >> 5;
     unsigned afo[KS][TM], bfo[KS][TN];
@@ -518,25 +527,25 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + (lane & 31);
-        const unsigned b = sm0 + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+        const unsigned b = sm0 + (row >> 3) * (NST * 1024) + (row & 7) * 128 + ((h ^ ((row >> 1) & 7)) << 4);
 #pragma unroll
         for (int s4 = 0; s4 < KS; ++s4) afo[s4][i] = b ^ ((KS * kg + s4) << 5);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = (wn * TN + j) * 32 + (lane & 31);
-        const unsigned b = sm0 + A_BYTES + row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+        const unsigned b = sm0 + A_ALL + (row >> 3) * (NST * 1024) + (row & 7) * 128 + ((h ^ ((row >> 1) & 7)) << 4);
 #pragma unroll
         for (int s4 = 0; s4 < KS; ++s4) bfo[s4][j] = b ^ ((KS * kg + s4) << 5);
     }
     frag_t fa[4][TM], fb[4][TN];          // KG = 1: one set per k-step; KG = 2: sets {0, 1} and {2, 3} alternate between K-blocks
-    auto load_set = [&](auto sc, auto kc, unsigned bufoff) {       // set sc <- k-step kc (of this group's KS) of the stage at bufoff
-        constexpr int s4 = decltype(sc)::value, k4 = decltype(kc)::value;
+    auto load_set = [&](auto sc, auto kc, auto stc) {              // set sc <- k-step kc (of this group's KS) of ring slot stc
+        constexpr int s4 = decltype(sc)::value, k4 = decltype(kc)::value, OFF = decltype(stc)::value * 1024;
         if (P2P_ABL == 1) return;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) lds_read16(fa[s4][i], afo[k4][i] + bufoff);
+        for (int i = 0; i < TM; ++i) lds_read16_off<OFF>(fa[s4][i], afo[k4][i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) lds_read16(fb[s4][j], bfo[k4][j] + bufoff);
+        for (int j = 0; j < TN; ++j) lds_read16_off<OFF>(fb[s4][j], bfo[k4][j]);
     };
     auto mfma_set = [&](auto sc) {
         constexpr int s4 = decltype(sc)::value;
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
     // MFMAs of the sets S0 .. S0 + NS - 1 with one LDS-DMA piece of the stage being requested behind each of the first NL of
     // them.  The MFMAs are unconditional (one code path: accumulators that live across a branch with MFMAs in both arms were
     // copied register by register at the join); only the tiny LDS-DMA issues sit under the wave-uniform `more`.
-    auto mfma_dma = [&](auto s0c, auto nsc, const bool more, char* buf) {
+    auto mfma_dma = [&](auto s0c, auto nsc, const bool more, int buf) {
         constexpr int S0 = decltype(s0c)::value, NS = decltype(nsc)::value;
         igemm_static_for(std::make_integer_sequence<int, NS * NMF>{}, [&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -569,44 +578,50 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
     // ---- prologue: stages 0 .. NST-2 requested, stage 0 landed (barrier), stage NST-1 requested, first fragment sets requested -------
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
-        if (st < nkb) stage_all(st, smem + st * STAGE);
+        if (st < nkb) stage_all(st, st);
     vm_wait_stages(min(NST - 2, nkb - 1));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (NST - 1 < nkb) stage_all(NST - 1, smem + (NST - 1) * STAGE);
+    if (NST - 1 < nkb) stage_all(NST - 1, NST - 1);
+    // The K loop is unrolled over the ring: K-block `it` lives in ring slot it % NST, a compile-time constant in every copy.
     if constexpr (KG == 1) {
         // four sets, one per k-step; the MFMAs of k-steps 2 and 3 run behind the barrier that ends the K-block
-        load_set(I0{}, I0{}, 0);
-        for (int it = 0; it < nkb; ++it) {
-            const unsigned cur = (unsigned)((it % NST) * STAGE);
-            char* const nbuf = smem + cur;                              // the buffer this iteration releases takes stage it + NST
+        auto kblock = [&](auto stc, int it) {
+            constexpr int ST = decltype(stc)::value;
+            using NX = std::integral_constant<int, (ST + 1) % NST>;
             __builtin_amdgcn_sched_barrier(0);
-            load_set(I1{}, I1{}, cur); lgkm_wait<NF>(); mfma_set(I0{});
+            load_set(I1{}, I1{}, stc); lgkm_wait<NF>(); mfma_set(I0{});
             __builtin_amdgcn_sched_barrier(0);
-            load_set(I2{}, I2{}, cur); lgkm_wait<NF>(); mfma_set(I1{});
+            load_set(I2{}, I2{}, stc); lgkm_wait<NF>(); mfma_set(I1{});
             __builtin_amdgcn_sched_barrier(0);
-            load_set(I3{}, I3{}, cur);
+            load_set(I3{}, I3{}, stc);
             const bool more = it + NST < nkb;                           // wave-uniform
             if (more) stage_prepare(it + NST);                          // scalar work under the waits below
             // stage it + 1 must have landed before anybody reads it; the younger stages may stay in flight
             vm_wait_stages(min(NST - 2, nkb - 2 - it));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // sets 2 and 3 are in registers: this stage's buffer may be overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // sets 2 and 3 are in registers: this slot may be overwritten
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (it + 1 < nkb) load_set(I0{}, I0{}, (unsigned)(((it + 1) % NST) * STAGE));
+            if (it + 1 < nkb) load_set(I0{}, I0{}, NX{});
             __builtin_amdgcn_sched_barrier(0);
-            mfma_dma(I2{}, I2{}, more, nbuf);
-        }
+            mfma_dma(I2{}, I2{}, more, ST);                             // the slot this K-block releases takes K-block it + NST
+        };
+        load_set(I0{}, I0{}, I0{});
+        for (int it0 = 0; it0 < nkb; it0 += NST)
+            igemm_static_for(std::make_integer_sequence<int, NST>{}, [&](auto stc) {
+                if (it0 + decltype(stc)::value < nkb) kblock(stc, it0 + decltype(stc)::value);
+            });
     } else {
         // two K groups share every K-block (group kg: k-steps 2 kg, 2 kg + 1): stages stay 32 KB, so a ring of four leaves three
         // K-blocks (96 KB per CU) in flight -- the launch is fed from HBM / the Infinity Cache, whose latency one 64 KB stage in
         // flight did not cover (r04: 43 us with warm caches but 60 us inside the step, against 52 / 57 us for the r03 kernel).
         // Per K-block and wave: MFMAs of k-step 0 | barrier | reads of the next block's two sets | MFMAs of k-step 1 + LDS-DMA.
-        auto body = [&](auto pc, int it) {
-            constexpr int P = decltype(pc)::value;
+        static_assert(KG == 1 || NST % 2 == 0, "the fragment sets alternate with the K-block's parity");
+        auto kblock = [&](auto stc, int it) {
+            constexpr int ST = decltype(stc)::value, P = ST & 1;
+            using NX = std::integral_constant<int, (ST + 1) % NST>;
             using X0 = std::integral_constant<int, 2 * P>; using X1 = std::integral_constant<int, 2 * P + 1>;
             using Y0 = std::integral_constant<int, 2 - 2 * P>; using Y1 = std::integral_constant<int, 3 - 2 * P>;
-            char* const nbuf = smem + (it % NST) * STAGE;
             const bool more = it + NST < nkb;
             __builtin_amdgcn_sched_barrier(0);
             lgkm_wait<NF>();                                            // X0 has landed (X1 behind it)
@@ -618,19 +633,18 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (it + 1 < nkb) {
-                const unsigned nxt = (unsigned)(((it + 1) % NST) * STAGE);
-                load_set(Y0{}, I0{}, nxt);
-                load_set(Y1{}, I1{}, nxt);
+                load_set(Y0{}, I0{}, NX{});
+                load_set(Y1{}, I1{}, NX{});
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma_dma(X1{}, I1{}, more, nbuf);
+            mfma_dma(X1{}, I1{}, more, ST);
         };
-        load_set(I0{}, I0{}, 0);
-        load_set(I1{}, I1{}, 0);
-        for (int it = 0; it < nkb; it += 2) {
-            body(I0{}, it);
-            if (it + 1 < nkb) body(I1{}, it + 1);
-        }
+        load_set(I0{}, I0{}, I0{});
+        load_set(I1{}, I1{}, I0{});
+        for (int it0 = 0; it0 < nkb; it0 += NST)
+            igemm_static_for(std::make_integer_sequence<int, NST>{}, [&](auto stc) {
+                if (it0 + decltype(stc)::value < nkb) kblock(stc, it0 + decltype(stc)::value);
+            });
     }
     __builtin_amdgcn_sched_barrier(0);
 
