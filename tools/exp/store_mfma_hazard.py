@@ -15,6 +15,7 @@ import sys
 
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 WINDOW = 1500          # instructions
+LDS_TOO = False        # --lds: the same question for ds_write data registers (until lgkmcnt(0))
 
 
 def regs(tok):
@@ -46,13 +47,19 @@ def scan_kernel(name, lines):
     hits = []
     for i, (ln, t) in enumerate(ins):
         op = t.split()[0]
-        if not (op.startswith("global_store") or op.startswith("buffer_store") or op.startswith("flat_store") or op.startswith("scratch_store")):
+        is_lds = op.startswith("ds_write")
+        if not (is_lds or op.startswith("global_store") or op.startswith("buffer_store") or op.startswith("flat_store") or op.startswith("scratch_store")):
+            continue
+        if is_lds and not LDS_TOO:
             continue
         ops = [o.strip() for o in t[len(op):].split(",")]
         if op.startswith("buffer_store"):
             data, addr = regs(ops[0]), regs(ops[1]) if len(ops) > 1 else None
         else:
             addr, data = regs(ops[0]), regs(ops[1]) if len(ops) > 1 else None
+            if is_lds and len(ops) > 2 and regs(ops[2]) and "offset" not in ops[2]:      # ds_write2: two data operands
+                d2 = regs(ops[2])
+                data = (min(data[0], d2[0]), max(data[1], d2[1])) if data else d2
         j, steps, jumped = i + 1, 0, set()
         # registers the store may still have to read; a vector instruction's or an LDS/VMEM return's write to one of them is
         # interlocked by the hardware (it waits for the read), so it takes the register off the list
@@ -62,7 +69,9 @@ def scan_kernel(name, lines):
             oj = tj.split()[0]
             if oj == "s_endpgm":
                 break
-            if oj == "s_waitcnt" and "vmcnt(0)" in tj:
+            if oj == "s_waitcnt" and ("lgkmcnt(0)" if is_lds else "vmcnt(0)") in tj:
+                break
+            if is_lds and oj == "s_barrier":
                 break
             if oj.startswith("v_mfma") or oj.startswith("v_smfma"):
                 dst = regs(tj[len(oj):].split(",")[0])
@@ -93,7 +102,11 @@ def scan_kernel(name, lines):
 
 
 def main():
+    global LDS_TOO
     total = 0
+    if "--lds" in sys.argv:
+        LDS_TOO = True
+        sys.argv.remove("--lds")
     for path in sys.argv[1:]:
         cur, buf, out = None, [], []
         for ln, t in enumerate(open(path), 1):
