@@ -12,13 +12,22 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = {"igemm_kernel": "p2p_igemm", "brig_kernel": "p2p_igemm", "wgemm_kernel": "p2p_wgemm", "norm_act_fwd_vec": "p2p_norm_act_fwd",
-            "norm_act_bwd_vec": "p2p_norm_act_bwd", "adam_flat_dev_kernel": "p2p_adam_flat_dev",
-            "weight_prep_kernel": "p2p_weight_prep_pad", "rgbuv_hist_fwd_kernel": "p2p_rgbuv_hist_fwd",
-            "rgbuv_hist_bwd_kernel": "p2p_rgbuv_hist_hellinger_bwd", "rgbuv_hist_fwd3_kernel": "p2p_rgbuv_hist_fwd3",
-            "rgbuv_hist_bwd3_kernel": "p2p_rgbuv_hist_hellinger_bwd3", "head_softmax_kernel": "p2p_head_softmax_cce",
-            "head_dgrad_kernel": "p2p_head_dgrad", "wgrad_small_kernel": "p2p_wgrad_small", "conv_strip_kernel": "p2p_conv_strip",
-            "conv_fewin_kernel": "p2p_conv_fewin", "conv_fewout_kernel": "p2p_conv_fewout"}
+# kernel-name fragment -> (C-ABI entry point, counts as a launch of it?).  Helper kernels of an entry point (slab sums, folds, prep)
+# add their bytes to the entry's total but not to its launch count, so "per launch" means per C-ABI call as in bench.py.
+FAMILIES = {"igemm_pipe_kernel": ("p2p_igemm", True), "igemm_kernel": ("p2p_igemm", True), "brig_kernel": ("p2p_igemm", True),
+            "wgemm_pipe_kernel": ("p2p_wgemm", True), "wgemm_kernel": ("p2p_wgemm", True),
+            "ws_slab_sum_kernel": ("p2p_wgrad_small", False), "slab_sum_kernel": ("p2p_wgemm", False),
+            "norm_act_fwd_vec": ("p2p_norm_act_fwd", True), "norm_act_fwd_small": ("p2p_norm_act_fwd", True),
+            "norm_act_bwd_vec": ("p2p_norm_act_bwd", True), "norm_act_bwd_small": ("p2p_norm_act_bwd", True),
+            "adam_flat_dev_kernel": ("p2p_adam_flat_dev", True),
+            "weight_prep_kernel": ("p2p_weight_prep_pad", True), "rgbuv_hist_fwd_kernel": ("p2p_rgbuv_hist_fwd", True),
+            "rgbuv_hist_bwd_kernel": ("p2p_rgbuv_hist_hellinger_bwd", True), "rgbuv_hist_fwd3_kernel": ("p2p_rgbuv_hist_fwd3", True),
+            "rgbuv_hist_fold_kernel": ("p2p_rgbuv_hist_fwd3", False),
+            "rgbuv_hist_bwd3_kernel": ("p2p_rgbuv_hist_hellinger_bwd3", True), "hist_grad_prep_kernel": ("p2p_rgbuv_hist_hellinger_bwd3", False),
+            "head_softmax_kernel": ("p2p_head_softmax_cce", True),
+            "head_dgrad_kernel": ("p2p_head_dgrad", True), "wgrad_small_kernel": ("p2p_wgrad_small", True),
+            "conv_strip_kernel": ("p2p_conv_strip", True),
+            "conv_fewin_kernel": ("p2p_conv_fewin", True), "conv_fewout_kernel": ("p2p_conv_fewout", True)}
 
 
 def load(folder, counter):
@@ -32,14 +41,15 @@ def load(folder, counter):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = row.get("Kernel_Name", "")
-                fam = next((v for k, v in FAMILIES.items() if k in name), None)
-                if fam is None:
+                hit = next((v for k, v in FAMILIES.items() if k in name), None)       # first match: the longer fragments come first
+                if hit is None:
                     continue
-                # GEN (edge) instantiations of igemm are a different entry point
-                if fam == "p2p_igemm" and ("Lb1ELb" in name or ", true," in name):
+                fam, primary = hit
+                # GEN (edge) instantiations of igemm_kernel are a different entry point
+                if fam == "p2p_igemm" and "igemm_kernel" in name and ("Lb1ELb" in name or ", true," in name):
                     fam = "p2p_igemm_edge"
                 per[fam][0] += float(row["Counter_Value"])
-                per[fam][1] += 1
+                per[fam][1] += 1 if primary else 0
     return per
 
 
