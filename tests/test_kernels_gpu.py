@@ -146,6 +146,37 @@ def test_conv_strip_up6(n, lh):
         assert U.rel_err(got, U.dense_to_np(out2)) < 1e-2 * OUT_TOL[dtype] + 4e-3, op     # same products, different f32 summation order
 
 
+def test_conv_strip_is_reproducible_launch_to_launch():
+    """p2p_conv_strip stores a tile and starts the next tile's MFMAs in the same wave.  Round 4 found that an MFMA's write-back is not
+    interlocked against a pending global store's read of its data registers; the kernel zeroes its accumulators
+    with vector moves since.  150 launches per direction at the c2 launch shape (B = 256, persistent workgroups, memory path loaded),
+    bit for bit."""
+    dtype, n, lh, cg, cd = L.BF16, 256, 32, 32, 128
+    g = torch.Generator(device=U.DEV).manual_seed(5)
+    hi_b, lo_b = E.HaloBuf(n, 2 * lh, 2 * lh, cg, dtype, U.DEV), E.HaloBuf(n, lh, lh, cd, dtype, U.DEV)
+    hi_b.t[:, 2:-2, 2:-2, :] = torch.randn((n, 2 * lh, 2 * lh, cg), device=U.DEV, generator=g).to(U.tdt(dtype))
+    lo_b.t[:, 2:-2, 2:-2, :] = torch.randn((n, lh, lh, cd), device=U.DEV, generator=g).to(U.tdt(dtype))
+    w_d = (0.05 * torch.randn(16 * cg * cd, device=U.DEV, generator=g)).float()
+    wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
+    L.call("p2p_weight_prep", dtype, U.ptr(w_d), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
+    for op, shape in ((L.OP_G, (n, lh, lh, cd)), (L.OP_P, (n, 2 * lh, 2 * lh, cg))):
+        slots = L.lib().p2p_conv_strip_stat_slots(op, dtype, n, lh, lh, cg, cd)
+        spart = torch.empty((max(n * slots * cg * 2, 4),), dtype=torch.float32, device=U.DEV)
+        first = None
+        for i in range(150):
+            out = E.DenseBuf(*shape, U.tdt(dtype), U.DEV)
+            out.t.fill_(float("nan"))
+            hv, lv = (hi_b.view(), out.view()) if op == L.OP_G else (out.view(), lo_b.view())
+            L.call("p2p_conv_strip", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), U.ptr(wt if op == L.OP_G else wn),
+                   U.ptr(spart) if slots else None, U.stream())
+            if first is None:
+                first = out.t.clone()
+                assert bool(torch.isfinite(first.float()).all())
+            else:
+                assert bool((out.t == first).all()), (op, i)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,msplit", [(2, 4, 32, 128, 1), (2, 8, 64, 128, 2), (3, 4, 128, 256, 1), (1, 1, 128, 128, 1),
                                                 (2, 16, 32, 128, 4), (5, 2, 64, 256, 1),
