@@ -130,6 +130,45 @@ def kernel_profile(eng, run_step, n_steps=3):
     return {k: {"ms_per_step": v[0] / n_steps, "launches_per_step": v[1] / n_steps} for k, v in agg.items()}, records
 
 
+def issue_profile(eng, run_step, n, replay=True, one_stream=False):
+    """How the step was fed (a driver line must say by itself whether the step was host-fed, overlapped or neither).
+    Issues n steps WITHOUT synchronising and times the issue loop and the drain separately: `issue_ms_per_step` is what the host
+    needs per step (median: the runtime makes the host wait for a whole batch of steps now and then, once its queue is ~50 steps
+    deep -- those waits are device time, not host time), `wall_ms_per_step` the device-limited step time of that mode.
+    replay=False: Python/ctypes per launch instead of one p2p_replay call; one_stream=True: no side streams, no events."""
+    was = (eng.replay_enabled, eng.side.enabled, eng.side_hist.enabled)
+    eng.replay_enabled = replay
+    if one_stream:
+        eng.side.enabled = eng.side_hist.enabled = False
+    try:
+        for _ in range(3):          # first step of a key is eager, the second is recorded, the third replays
+            run_step()
+        torch.cuda.synchronize()
+        ts = [time.perf_counter()]
+        for _ in range(n):
+            run_step()
+            ts.append(time.perf_counter())
+        torch.cuda.synchronize()
+        t_end = time.perf_counter()
+    finally:
+        eng.replay_enabled, eng.side.enabled, eng.side_hist.enabled = was
+    d = np.diff(np.array(ts)) * 1e3
+    return {"issue_ms_per_step": round(float(np.median(d)), 4), "issue_ms_per_step_mean": round(float(d.mean()), 4),
+            "drain_ms": round(1e3 * (t_end - ts[-1]), 3), "wall_ms_per_step": round(1e3 * (t_end - ts[0]) / n, 4)}
+
+
+def _host_info():
+    info = {"cpus": os.cpu_count()}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +179,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-feed-profile", action="store_true", help="skip the host-issue / one-stream measurements after the timed loop")
+    ap.add_argument("--no-replay", action="store_true", help="issue every launch from Python (P2P_REPLAY=0) instead of one p2p_replay call per step")
+    ap.add_argument("--one-stream", action="store_true", help="no weight-gradient / histogram side streams")
     ap.add_argument("--no-mfma", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one captured hipGraph (N=1 only). Measured "
                     "slower than eager two-stream launching on ROCm 7.2 (the replay serialises the weight-gradient branch), so off by default")
@@ -189,6 +231,10 @@ def main():
         src, tgt = synthetic_batch(rank, B, S, palette)
     src_d = torch.as_tensor(src).to(device)
     tgt_d = torch.as_tensor(tgt).to(device)
+    if args.no_replay:
+        eng.replay_enabled = False
+    if args.one_stream:
+        eng.side.enabled = eng.side_hist.enabled = False
 
     def run_step_eager():
         if indexed:
@@ -230,7 +276,8 @@ def main():
                                + ("palette-index sprites (1 -> 256-way softmax), " f"lambda_seg={lam_l1}" if indexed else
                                   "RGBA sprites, " f"lambda_l1={lam_l1}") + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
                    "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if use_graph else "eager",
+                   "launch": "hipGraph replay" if use_graph else ("one p2p_replay call per step" if eng._replays else "eager (Python/ctypes per launch)"),
+                   "streams": 1 if not eng.side.enabled else (3 if lam_hist else 2),
                    **({"rccl": _collective_info(), "grad_buckets": len(eng.G.buckets)} if world > 1 else {})},
         "losses": [round(float(x), 5) for x in losses.cpu().numpy()],
     }
@@ -239,6 +286,20 @@ def main():
         flops_img = FL.train_step_flops_per_image(S, 1, 256, indexed=True) if indexed else FL.train_step_flops_per_image(S, 4, 4)
         result["conv_tflops"] = round(flops_img * value / 1e12, 2)
         result["conv_mfma_frac_of_peak"] = round(flops_img * value / 1e12 / (MFMA_PEAK[args.dtype] * world), 4)
+        if not args.no_feed_profile and not use_graph:
+            # how the step was fed, measured in this process right after the timed loop (rank 0's LOCAL step, no collectives)
+            def run_step_feed():
+                if indexed:
+                    return eng.train_step_indexed(src_d, tgt_d, lam_l1, global_batch=B)
+                return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B)
+            n_feed = max(10, min(args.steps, 40))
+            feed = {"replayed": issue_profile(eng, run_step_feed, n_feed), "eager": issue_profile(eng, run_step_feed, n_feed, replay=False),
+                    "one_stream": issue_profile(eng, run_step_feed, n_feed, one_stream=True), "host": _host_info()}
+            result["host_issue_ms_per_step"] = feed["replayed"]["issue_ms_per_step"]
+            result["host_issue_ms_per_step_eager"] = feed["eager"]["issue_ms_per_step"]
+            result["ms_per_step_eager_issue"] = feed["eager"]["wall_ms_per_step"]
+            result["ms_per_step_one_stream"] = feed["one_stream"]["wall_ms_per_step"]
+            result["feed"] = feed
         if not args.no_profile:
             # per-call device times of rank 0's LOCAL step (no collectives: the other ranks are already at the barrier)
             def run_step_local():
@@ -247,6 +308,8 @@ def main():
                 return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B)
             prof, records = kernel_profile(eng, run_step_local)
             result["kernel_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+            # every launch of a step on ONE stream with an event pair around it: what the step would take with no overlap at all
+            result["serialised_kernel_ms"] = round(sum(v["ms_per_step"] for v in prof.values()), 4)
             result["roofline"] = FL.roofline_for_dominant(prof, records, B, S, args.dtype)
             # every entry point that matters, each against the roofline that bounds it (bf16 / exact-f32 MFMA peak, or HBM)
             result["rooflines"] = FL.rooflines_top(prof, records, args.dtype, k=10)

@@ -457,6 +457,29 @@ int p2p_event_destroy(void* ev);
 int p2p_event_record(void* ev, void* stream);            /* marks the work issued so far on `stream` */
 int p2p_stream_wait_event(void* stream, void* ev);       /* later work on `stream` waits for the event's latest record */
 
+/* ---- step replay (the reference runs train_step as ONE traced tf.function, pix2pix_model.py:62: a step costs the host one
+ * call, not one per op; side2side_model.py:73,114 is the loop that issues it) -------------------------------------------------
+ * A train step is ~105 kernel entry points and ~40 stream operations whose arguments do not change from step to step (persistent
+ * buffers, explicit stream handles).  The host records them once as an array of p2p_replay_call and re-issues the whole step
+ * with ONE p2p_replay call: the same entry points, in the same order, on the same streams -- bit-identical results, no
+ * interpreter between two launches.  `fn` = p2p_replay_fn_index(name of an entry point of this header that returns int and takes
+ * only scalars and pointers); a[k] = argument k in an 8-byte slot (ints and floats in the low bytes, little endian).  Bit k of
+ * `ind64` / `ind32` set: a[k] is the ADDRESS of a host variable of 8 / 4 bytes that is read when the call is replayed (the batch
+ * pointers, the result pointer, the optimizer's hyper-parameters: what may change between two steps of one recording).
+ * Structures passed by pointer (p2p_tensor, p2p_gsrc) are read at replay time like any other pointer argument: the host keeps
+ * them alive.  Returns 0, or the first failing call's code with p2p_last_error() naming the call's index and entry point. */
+#define P2P_REPLAY_MAX_ARGS 24
+typedef struct {
+    int fn;
+    int nargs;
+    unsigned ind64;
+    unsigned ind32;
+    unsigned long long a[P2P_REPLAY_MAX_ARGS];
+} p2p_replay_call;
+int p2p_replay_fn_index(const char* name);      /* -1: not a replayable entry point */
+int p2p_replay_fn_nargs(int fn);
+int p2p_replay(const p2p_replay_call* calls, int n);
+
 /* ---- input pipeline (reference dataset_utils.py:11-20,39-49,66-120,209-246) ---------------------------- */
 
 /* Host helper (no GPU): undo the PNG scanline filters of an inflated IDAT stream (height rows of 1 + row_bytes bytes, 8-bit

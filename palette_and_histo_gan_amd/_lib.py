@@ -94,7 +94,9 @@ SIGNATURES = {
     "p2p_gather_rows_i32": [_vp, _i, _i, _vp, _i, _vp, _vp],
     "p2p_palette_relabel_batch": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
 }
-SPECIAL = {"p2p_last_error": ([], C.c_char_p), "p2p_version": ([], C.c_int), "p2p_view_halo_pixels": ([], C.c_int),
+SPECIAL = {"p2p_last_error": ([], C.c_char_p),
+           "p2p_replay_fn_index": ([C.c_char_p], C.c_int), "p2p_replay_fn_nargs": ([_i], C.c_int),
+           "p2p_replay": ([_vp, _i], C.c_int), "p2p_version": ([], C.c_int), "p2p_view_halo_pixels": ([], C.c_int),
            "p2p_igemm_stat_slots": ([_i, _i, _i, _i, _i], C.c_int),
            "p2p_brig_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_igemm_norm_act_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),

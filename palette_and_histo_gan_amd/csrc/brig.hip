@@ -626,7 +626,7 @@ int brig_launch(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const 
 #define BRIG_GO(M, CB, R)                                                                                                          \
     do {                                                                                                                           \
         static bool attr = false;                                                                                                  \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)brig_kernel<M, CB, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        if (!attr) attr = p2p_allow_lds((const void*)brig_kernel<M, CB, R>, 160 * 1024, "brig_kernel");                          \
         brig_kernel<M, CB, R><<<grid, dim3(512), p.shm, st>>>(a);                                                                  \
     } while (0)
     switch (key) {

@@ -13,8 +13,23 @@ void p2p_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_attr_err[256] = "";
+
+bool p2p_allow_lds(const void* kernel, int bytes, const char* name) {
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) return true;
+    (void)hipGetLastError();
+    snprintf(g_attr_err, sizeof(g_attr_err), "%s: %d bytes of dynamic LDS refused (%s)", name, bytes, hipGetErrorString(e));
+    return false;
+}
+
 int p2p_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
+    if (g_attr_err[0]) {        // the launch that followed a refused attribute: say why it failed
+        p2p_set_error("%s: %s", what, g_attr_err);
+        g_attr_err[0] = 0;
+        return e != hipSuccess ? (int)e : -2;
+    }
     if (e != hipSuccess) {
         p2p_set_error("%s: %s", what, hipGetErrorString(e));
         return (int)e;

@@ -255,10 +255,7 @@ extern "C" int p2p_conv_fewout(int op, int stride, int dtype, int N, int LH, int
 #define FO_GO(KS_, OS_)                                                                                                \
     do {                                                                                                               \
         static bool done = false;                                                                                      \
-        if (!done) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)conv_fewout_kernel<T, KS_, OS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            done = true;                                                                                               \
-        }                                                                                                              \
+        if (!done) done = p2p_allow_lds((const void*)conv_fewout_kernel<T, KS_, OS_>, 160 * 1024, "conv_fewout_kernel");  \
         conv_fewout_kernel<T, KS_, OS_><<<grid, dim3(512), p.shm, st>>>(a);                                            \
     } while (0)
     if (p.KS == 3 && p.OS == 4) { P2P_DISPATCH_DTYPE(dtype, FO_GO(3, 4)); }

@@ -15,6 +15,11 @@ typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
 
 void p2p_set_error(const char* fmt, ...);
 int p2p_check_launch(const char* what);
+// Raises a kernel's dynamic-LDS limit above the default 64 KB (hipFuncAttributeMaxDynamicSharedMemorySize).  Returns true on
+// success; a refusal is remembered and reported, with the kernel's name and the byte count, by the p2p_check_launch that follows
+// the launch -- which would otherwise fail with an unexplained "invalid argument".  Callers keep their "done" flag false on
+// failure, so the next call tries (and reports) again.
+bool p2p_allow_lds(const void* kernel, int bytes, const char* name);
 
 #define P2P_REQUIRE(cond, ...)                 \
     do {                                       \

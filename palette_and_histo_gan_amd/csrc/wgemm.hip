@@ -388,6 +388,10 @@ __global__ __launch_bounds__(512) void wgemm_pipe_kernel(WgemmArgs a) {
         if (it + 1 < nit) body(I1{}, it + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // (no fragment read or LDS-DMA piece is outstanding after the last stage; said explicitly because the swap below re-uses the
+    // fragment registers and nothing interlocks a vector write against a pending LDS return: tools/exp/asm_checks.py)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- K groups: every wave sends its odd fragment row and keeps the even one (group 1 swaps first: static register indices) -------
     if (kg) {
@@ -492,7 +496,7 @@ static int wgemm_launch(WgemmArgs& a, int msplit, hipStream_t st) {
     const int cg = a.Cg, cd = a.Cd;
     if (wgemm_pipe_ok(a, ESZ, msplit)) {
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)wgemm_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        if (!attr) attr = p2p_allow_lds((const void*)wgemm_pipe_kernel<4>, 160 * 1024, "wgemm_pipe_kernel");
         dim3 grid(16 * (cg / 128), cd / 128, msplit);
         wgemm_pipe_kernel<4><<<grid, dim3(512), 4 * 32768, st>>>(a);
         return p2p_check_launch("p2p_wgemm");

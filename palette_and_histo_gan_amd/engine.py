@@ -41,29 +41,93 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# Host-side step replay (launch-bound small batches: fit() at the reference's BATCH_SIZE = 4).  A train step is ~110 C-ABI calls
-# and ~40 stream operations whose arguments do not change from step to step (persistent buffers, cached descriptors, explicit
-# stream handles) except the batch pointers and the result tensor, which live in re-usable ctypes slots.  While _REC holds a list,
-# every kernel call (through _rec_call) and every stream operation (through _op) appends itself; Pix2PixEngine._replay() then
-# re-issues the list without the Python between the calls.  Same kernels, same order, same streams: results are bit-identical.
+# Step replay.  A train step is ~105 C-ABI kernel calls and ~40 stream operations whose arguments do not change from step to step
+# (persistent buffers, cached descriptors, explicit stream handles) except the batch pointers, the result pointer and the
+# optimizer's hyper-parameters, which live in re-usable ctypes slots.  While _REC holds a list every call (through _rec_call) and
+# every stream operation (through _op) appends itself; the list is then packed into an array of p2p_replay_call records
+# (include/p2pgan.h) and Pix2PixEngine._replay() re-issues the whole step with ONE call into the library -- no interpreter between
+# two launches.  Same entry points, same order, same streams: results are bit-identical.  (The reference's train_step is one traced
+# tf.function, pix2pix_model.py:62: its host pays one call per step too.)
 _REC = [None]
 _ORIG_CALL = L.call
 
 
 def _rec_call(name, *args):
-    """L.call while a step is being recorded: run the entry point and remember (function, arguments)"""
+    """L.call while a step is being recorded: run the entry point and remember (name, arguments)"""
     fn = getattr(L.lib(), name)
     rc = fn(*args)
     if rc != 0:
         raise L.P2PError(f"{name} failed (rc={rc}): {L.lib().p2p_last_error().decode()}")
-    _REC[0].append((fn, args, name))
+    _REC[0].append((name, args))
 
 
-def _op(fn):
-    """run a stream operation now and, while a step is being recorded, remember it (explicit stream / event objects inside)"""
-    fn()
+def _op(name, *args):
+    """a stream operation (p2p_event_record / p2p_stream_wait_event with explicit stream and event handles): run it now and,
+    while a step is being recorded, remember it"""
+    if getattr(L.lib(), name)(*args) != 0:
+        raise L.P2PError(f"{name} failed: " + L.lib().p2p_last_error().decode())
     if _REC[0] is not None:
-        _REC[0].append((None, fn, None))
+        _REC[0].append((name, args))
+
+
+class ReplayCall(C.Structure):
+    """include/p2pgan.h p2p_replay_call"""
+    MAX_ARGS = 24
+    _fields_ = [("fn", C.c_int), ("nargs", C.c_int), ("ind64", C.c_uint), ("ind32", C.c_uint), ("a", C.c_ulonglong * 24)]
+
+
+_M64 = (1 << 64) - 1
+_F32 = __import__("struct").Struct("<f")
+_U32 = __import__("struct").Struct("<I")
+
+
+def _pack_arg(argtype, v):
+    """one recorded ctypes argument as (8-byte slot, indirection width): what ctypes would hand to the entry point.  A ctypes
+    scalar OBJECT (c_void_p / c_float / c_longlong instance) is read when the call is issued, exactly as ctypes does -- the
+    engine's batch, result and hyper-parameter slots rely on that -- so it is packed as the object's address."""
+    if isinstance(v, C._SimpleCData):
+        width = C.sizeof(v)
+        if width not in (4, 8):
+            raise TypeError(f"cannot replay a {type(v).__name__} argument")
+        return C.addressof(v), width
+    if argtype is C.c_float:
+        return _U32.unpack(_F32.pack(v))[0], 0
+    if argtype in (C.c_int, C.c_longlong):
+        return int(v) & _M64, 0
+    # pointers: void* and pointers to structures
+    if v is None:
+        return 0, 0
+    if isinstance(v, int):
+        return v & _M64, 0
+    if isinstance(v, (C.Structure, C.Array)):
+        return C.addressof(v), 0
+    obj = getattr(v, "_obj", None)          # C.byref(x)
+    if obj is not None:
+        return C.addressof(obj), 0
+    raise TypeError(f"cannot replay an argument of type {type(v).__name__}")
+
+
+def pack_replay(rec):
+    """list of (entry point name, ctypes arguments) -> (array of p2p_replay_call, n).  The caller keeps `rec` alive: the records
+    hold the addresses of the ctypes objects inside it."""
+    lib = L.lib()
+    arr = (ReplayCall * len(rec))()
+    for k, (name, args) in enumerate(rec):
+        types = L.SIGNATURES[name]
+        fn = lib.p2p_replay_fn_index(name.encode())
+        if fn < 0 or len(args) != len(types) or lib.p2p_replay_fn_nargs(fn) != len(types):
+            raise L.P2PError(f"{name} with {len(args)} arguments is not replayable")
+        c = arr[k]
+        c.fn, c.nargs = fn, len(args)
+        i64 = i32 = 0
+        for j, (t, v) in enumerate(zip(types, args)):
+            c.a[j], ind = _pack_arg(t, v)
+            if ind == 8:
+                i64 |= 1 << j
+            elif ind == 4:
+                i32 |= 1 << j
+        c.ind64, c.ind32 = i64, i32
+    return arr, len(rec)
 
 
 # (stream ordering always uses device-only events, p2p_event_*: torch.cuda.Event.record carries a system-scope release that idled
@@ -89,13 +153,9 @@ def _raw(stream):
 
 def _order(after, before):
     """work issued to stream `after` from now on waits for everything issued so far on stream `before`"""
-    ev, a, b = _ring_event(), _raw(after), _raw(before)
-    rec, wait = L.lib().p2p_event_record, L.lib().p2p_stream_wait_event
-
-    def go():
-        if rec(ev, b) != 0 or wait(a, ev) != 0:
-            raise L.P2PError("stream ordering failed: " + L.lib().p2p_last_error().decode())
-    _op(go)
+    ev = _ring_event()
+    _op("p2p_event_record", ev, _raw(before))
+    _op("p2p_stream_wait_event", _raw(after), ev)
 
 
 class _SideStream:
@@ -122,20 +182,10 @@ class _SideStream:
 class _LightEvent:
     def __init__(self, st):
         self.ev = _ring_event()
-        ev, s, rec = self.ev, _raw(st), L.lib().p2p_event_record
-
-        def go():
-            if rec(ev, s) != 0:
-                raise L.P2PError("event record failed: " + L.lib().p2p_last_error().decode())
-        _op(go)
+        _op("p2p_event_record", self.ev, _raw(st))
 
     def wait(self, st):
-        ev, s, wait = self.ev, _raw(st), L.lib().p2p_stream_wait_event
-
-        def go():
-            if wait(s, ev) != 0:
-                raise L.P2PError("event wait failed: " + L.lib().p2p_last_error().decode())
-        _op(go)
+        _op("p2p_stream_wait_event", _raw(st), self.ev)
 
 
 def _record_event():
@@ -354,6 +404,7 @@ class Pix2PixEngine:
         self.G.grads = self._grad_all[:self.G.numel]
         self.D.grads = self._grad_all[self.G.numel:self.G.numel + self.D.numel]
         self.rng = np.random.default_rng(seed)
+        self._slot_seed = C.c_longlong()
         self.seed = int(seed)
         self.mask_counter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)    # advanced once per step on the device
         self._init_params()
@@ -364,6 +415,10 @@ class Pix2PixEngine:
         self.W = {}
         self._alloc_weight_copies()
         self.plans = {}
+        # Adam's hyper-parameters and the dropout seed live in ctypes slots (properties below): the entry points receive the slot
+        # object, ctypes -- and a replayed step -- read it when the call is issued, so ONE recorded step serves every value of a
+        # learning-rate schedule
+        self._slot_lr, self._slot_b1, self._slot_b2, self._slot_eps = C.c_float(), C.c_float(), C.c_float(), C.c_float()
         self.lr, self.beta1, self.beta2, self.adam_eps = 2e-4, 0.5, 0.999, 1e-7   # pix2pix_model.py:28-29
         self.losses = self._grad_all[self.G.numel + self.D.numel:]
         # per-workgroup partials of the loss kernels (include/p2pgan.h P2P_LOSS_BLOCKS): rows 0..2 BCE, row 3 L1 -- the
@@ -399,9 +454,10 @@ class Pix2PixEngine:
         # 0.187 ms for the flat Adam + batched copy launch on c2 (the tiled kernel streams slower than the flat one): off
         self.fuse_adam = False      # (no environment switch: tests/test_train_step_gpu.py toggles the attribute)
         self._adam_tables = {}
-        # host-side replay of the step's call list for launch-bound batches (see _REC above)
-        self.replay_max_batch = int(os.environ.get("P2P_REPLAY_MAX_BATCH", "32"))
-        self._replays, self._replay_seen = {}, {}
+        # replay of the recorded step through ONE library call (see _REC above), at every batch size
+        self.replay_max_batch = int(os.environ.get("P2P_REPLAY_MAX_BATCH", str(1 << 30)))
+        self._replays, self._replay_seen = OrderedDict(), {}
+        self._replay_fn = L.lib().p2p_replay
         self.replay_enabled = os.environ.get("P2P_REPLAY", "1") != "0"
         self._slot_src, self._slot_real, self._slot_out = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._real_view = L.Tensor(None, 0, 0, 4)
@@ -412,6 +468,18 @@ class Pix2PixEngine:
         self.hist_fwd3 = self.hist_bwd3 = self.hist_points = 1
         self.split_prep = int(os.environ.get("P2P_SPLIT_PREP", "1"))    # weight copies of the early-Adam part refreshed right behind it
         self.refresh_weight_copies()
+
+    def _slot_property(slot):
+        def get(self):
+            return getattr(self, slot).value
+
+        def put(self, v):
+            getattr(self, slot).value = v
+        return property(get, put)
+
+    lr, beta1, beta2 = _slot_property("_slot_lr"), _slot_property("_slot_b1"), _slot_property("_slot_b2")
+    adam_eps, seed = _slot_property("_slot_eps"), _slot_property("_slot_seed")
+    del _slot_property
 
     # ------------------------------------------------------------------ parameters
     def _init_params(self):
@@ -547,7 +615,7 @@ class Pix2PixEngine:
             return
         store = self.D if part == "D" else self.G
         L.call("p2p_adam_prep_batched", self.dtype, n_elems, _p(raw), ntasks, total, _p(store.params), _p(store.grads), _p(store.m),
-               _p(store.v), _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, _stream())
+               _p(store.v), _p(store.lr_t_dev), self._slot_b1, self._slot_b2, self._slot_eps, _stream())
 
     def refresh_weight_copies(self, part="all"):
         """Re-derives the per-layer weight copies from the f32 masters; runs after every Adam step (one launch per part)."""
@@ -929,20 +997,23 @@ class Pix2PixEngine:
         L.call("p2p_pack_input_multi", self.dtype, P["B"], self.S, self.S, c, ptr or _p(t), 1 if t.dtype == torch.int32 else 0,
                arr, len(views), _stream())
 
-    # -- host-side step replay (see _REC) ------------------------------------------------------------------------------
+    # -- step replay (see _REC) ------------------------------------------------------------------------------------------
+    REPLAY_CACHE = 8          # recorded steps kept per engine (least recently used goes first)
+
     def _replay_key(self, kind, B, masks, dp, apply_update, *extra):
-        """key of a replayable step, or None: device RNG masks, single GPU, with the optimizer step, launch-bound batch, and
-        nobody else instrumenting L.call (bench.py's per-call timing)"""
+        """key of a replayable step, or None: device RNG masks, single GPU, with the optimizer step, and nobody else
+        instrumenting L.call (bench.py's per-call timing)"""
         if (masks is not None or dp is not None or not apply_update or B > self.replay_max_batch or self.device.type != "cuda"
                 or L.call is not _ORIG_CALL or not self.replay_enabled or torch.cuda.is_current_stream_capturing()):
             return None
-        # everything the recorded calls hold BY VALUE: switches that choose kernels, the optimizer's hyper-parameters and the dropout
-        # seed (passed as scalars to p2p_adam_tick / p2p_adam_flat_dev / p2p_dropout_mask_dev), the K-split target and the stream the
-        # step was issued on (raw handles inside the recorded calls): a change of any of them records a new list
+        # everything the recorded calls hold BY VALUE: the switches that choose kernels, the K-split / grid targets and the stream
+        # the step was issued on (raw handle inside the records -- the id of the torch stream object rides along, so a recycled
+        # handle value of a NEW stream does not match an old recording).  Adam's hyper-parameters and the dropout seed are NOT
+        # part of the key: the records hold the address of their slots (_slot_lr ...), one recording serves every value.
+        st = torch.cuda.current_stream()
         return (kind, B, self.side.enabled, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
                 self.hist_points, self.fuse_act_bwd, self.split_prep, self.full_pixels, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
-                self.use_mfma, float(self.lr), float(self.beta1), float(self.beta2), float(self.adam_eps), int(self.seed),
-                int(self.splitk_target), int(self.wgemm_want), int(self.wgemm_want_pipe), int(torch.cuda.current_stream().cuda_stream)) + extra
+                self.use_mfma, int(self.splitk_target), int(self.wgemm_want), int(self.wgemm_want_pipe), int(st.cuda_stream), int(st.stream_id)) + extra
 
     def _bind_batch(self, src_t, real_t):
         """the batch tensors of this step behind the re-usable pointer slots the recorded calls hold"""
@@ -961,6 +1032,8 @@ class Pix2PixEngine:
         if key is None:
             return False
         n = self._replay_seen.get(key, 0)
+        if n == 0 and len(self._replay_seen) >= 8 * self.REPLAY_CACHE:
+            self._replay_seen.clear()
         self._replay_seen[key] = n + 1
         if n < 1:
             return False
@@ -972,16 +1045,19 @@ class Pix2PixEngine:
         rec, _REC[0] = _REC[0], None
         L.call = _ORIG_CALL
         if ok:
-            self._replays[key] = rec
+            arr, n = pack_replay(rec)
+            self._replays[key] = (arr, n, rec)          # `rec` keeps every ctypes object alive whose address the records hold
+            while len(self._replays) > self.REPLAY_CACHE:
+                old, _ = self._replays.popitem(last=False)
+                self._replay_seen.pop(old, None)
 
-    def _replay(self, rec, P, src_t, real_t, hist=False):
+    def _replay(self, key, P, src_t, real_t, hist=False):
+        arr, n, _ = self._replays[key]
+        self._replays.move_to_end(key)
         self._bind_batch(src_t, real_t)
         out = self._new_out()
-        for fn, args, name in rec:
-            if fn is None:
-                args()
-            elif fn(*args) != 0:
-                raise L.P2PError(f"{name} failed: {L.lib().p2p_last_error().decode()}")
+        if self._replay_fn(arr, n) != 0:
+            raise L.P2PError(L.lib().p2p_last_error().decode())
         self.G.t += 1
         self.D.t += 1
         self.step_count += 1
@@ -1010,12 +1086,12 @@ class Pix2PixEngine:
                 for i, drop in enumerate(UP_DROPOUT, start=1):
                     if drop:
                         m = P["mask"][i]
-                        L.call("p2p_dropout_mask_dev", _p(m), m.numel(), self.seed, _p(self.mask_counter_dev), i,
+                        L.call("p2p_dropout_mask_dev", _p(m), m.numel(), self._slot_seed, _p(self.mask_counter_dev), i,
                                self._batch_offset * (m.numel() // P["B"]), _stream())
             if apply_update:
                 L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
                 for store in (self.G, self.D):
-                    L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
+                    L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self._slot_lr, self._slot_b1, self._slot_b2, _stream())
                 self._ticked = True
             P["early_masks"] = masks is None
             P["early_ev"] = None
@@ -1061,7 +1137,7 @@ class Pix2PixEngine:
                         _wait_event(P["early_ev"])
                         P["early_ev"] = None
                 else:       # Bernoulli(0.5) keep mask (networks.py:31-32), counter-based device RNG
-                    L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self.seed, _p(self.mask_counter_dev), i,
+                    L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self._slot_seed, _p(self.mask_counter_dev), i,
                            self._batch_offset * (mask.numel() // B), _stream())
             self._norm_fwd(P, B, 2 * lh, f, P["ru"][i], rk, self.G.p(f"up{i}.gamma"), self.G.p(f"up{i}.beta"),
                            L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i],
@@ -1120,7 +1196,7 @@ class Pix2PixEngine:
         key = self._replay_key("rgba", B, masks, dp, apply_update, float(lambda_l1),
                                None if lambda_hist is None else float(lambda_hist), Bg, int(batch_offset))
         if key in self._replays:
-            return self._replay(self._replays[key], P, src_t, real_t, hist=lambda_hist is not None)
+            return self._replay(key, P, src_t, real_t, hist=lambda_hist is not None)
         recording = self._begin_record(key)
         try:
             out = self._train_step_rgba_body(P, B, Bg, src_t, real_t, lambda_l1, lambda_hist, masks, apply_update, dp)
@@ -1321,7 +1397,7 @@ class Pix2PixEngine:
             self._head_prepped = True
             return n
         L.call("p2p_adam_flat_dev", _p(self.G.params), _p(self.G.grads), _p(self.G.m), _p(self.G.v), n,
-               _p(self.G.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+               _p(self.G.lr_t_dev), self._slot_b1, self._slot_b2, self._slot_eps, 1.0, _stream())
         if self.split_prep:
             # their weight copies too: the data-gradient kernels that read them are done (same stream), the other stream's
             # last weight gradients do not read weight copies -- a memory-bound launch beside MFMA-bound ones instead of
@@ -1338,7 +1414,7 @@ class Pix2PixEngine:
             for store in (self.G, self.D):
                 store.t += 1
                 if not ticked:
-                    L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
+                    L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self._slot_lr, self._slot_b1, self._slot_b2, _stream())
             if g_from == 0:
                 self._adam_prep("G_head")
             self._adam_prep("G_rest")
@@ -1347,7 +1423,7 @@ class Pix2PixEngine:
                 lo_e, hi_e = store.small_range
                 if hi_e > lo_e:
                     L.call("p2p_adam_flat_dev", _p(store.params, lo_e), _p(store.grads, lo_e), _p(store.m, lo_e), _p(store.v, lo_e),
-                           hi_e - lo_e, _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+                           hi_e - lo_e, _p(store.lr_t_dev), self._slot_b1, self._slot_b2, self._slot_eps, 1.0, _stream())
             raw, ntasks, total, _ = self._adam_table("extra")
             if ntasks:
                 L.call("p2p_weight_prep_batched", self.dtype, _p(raw), ntasks, total, _stream())
@@ -1358,10 +1434,10 @@ class Pix2PixEngine:
         for store in (self.G, self.D):
             store.t += 1
             if not ticked:
-                L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self.lr, self.beta1, self.beta2, _stream())
+                L.call("p2p_adam_tick", _p(store.t_dev), _p(store.lr_t_dev), self._slot_lr, self._slot_b1, self._slot_b2, _stream())
             off = g_from if store is self.G else 0
             L.call("p2p_adam_flat_dev", _p(store.params, off), _p(store.grads, off), _p(store.m, off), _p(store.v, off),
-                   store.numel - off, _p(store.lr_t_dev), self.beta1, self.beta2, self.adam_eps, 1.0, _stream())
+                   store.numel - off, _p(store.lr_t_dev), self._slot_b1, self._slot_b2, self._slot_eps, 1.0, _stream())
         if not ticked:
             L.call("p2p_counter_add", _p(self.mask_counter_dev), 1, _stream())
         head_done, self._head_prepped = self._head_prepped and g_from > 0, False
@@ -1467,7 +1543,7 @@ class Pix2PixEngine:
         real_t = self._to_device(real_idx, 1, B, is_int=True)
         key = self._replay_key("indexed", B, masks, dp, apply_update, float(lambda_segmentation), Bg, int(batch_offset))
         if key in self._replays:
-            return self._replay(self._replays[key], P, src_t, real_t)
+            return self._replay(key, P, src_t, real_t)
         recording = self._begin_record(key)
         try:
             out = self._train_step_indexed_body(P, B, Bg, src_t, real_t, lambda_segmentation, masks, apply_update)

@@ -129,3 +129,40 @@ def test_product_path_has_no_cpu_fallback():
     for mod in ("engine.py", "pix2pix_model.py", "networks.py", "side2side_model.py", "parallel.py", "_lib.py"):
         text = open(os.path.join(ROOT, "palette_and_histo_gan_amd", mod)).read()
         assert "import oracle" not in text and "from oracle" not in text, mod
+
+
+def test_replay_table_covers_the_int_entry_points_and_replays_host_calls():
+    """p2p_replay (include/p2pgan.h "step replay"): every int-returning entry point has a thunk whose argument count equals the
+    binding's; a recorded list is packed into p2p_replay_call records and issued by ONE call.  Exercised here with the one entry
+    point that needs no GPU (p2p_png_unfilter): by-value ints, pointers, a pointer slot that is re-read at every replay (the
+    mechanism behind the batch pointers), and the error path naming the failing call."""
+    lib = L.lib()
+    for name, argtypes in L.SIGNATURES.items():
+        fn = lib.p2p_replay_fn_index(name.encode())
+        assert fn >= 0, name
+        assert lib.p2p_replay_fn_nargs(fn) == len(argtypes) <= E.ReplayCall.MAX_ARGS, name
+    assert lib.p2p_replay_fn_index(b"p2p_last_error") == -1 and lib.p2p_replay_fn_index(b"p2p_replay") == -1
+    assert ctypes.sizeof(E.ReplayCall) == 16 + 8 * 24
+    h, rb, bpp = 3, 8, 4
+    rng = np.random.default_rng(0)
+    rows = rng.integers(0, 256, size=(h, rb), dtype=np.uint8)
+    filt = np.concatenate([np.array([[1], [2], [0]], np.uint8), rows], axis=1).copy()      # Sub, Up, None
+    want = np.zeros((h, rb), np.uint8)
+    assert lib.p2p_png_unfilter(filt.ctypes.data, h, rb, bpp, want.ctypes.data) == 0
+    out_a, out_b = np.zeros((h, rb), np.uint8), np.zeros((h, rb), np.uint8)
+    slot = ctypes.c_void_p(out_a.ctypes.data)
+    rec = [("p2p_png_unfilter", (ctypes.c_void_p(filt.ctypes.data), h, rb, bpp, slot)),
+           ("p2p_png_unfilter", (filt.ctypes.data, h, rb, ctypes.c_int(bpp), slot))]
+    arr, n = E.pack_replay(rec)
+    assert n == 2 and arr[0].ind64 == 0b10001 and arr[0].ind32 == 0 and arr[1].ind64 == 0b10000 and arr[1].ind32 == 0b01000
+    assert lib.p2p_replay(arr, n) == 0 and np.array_equal(out_a, want) and not out_b.any()
+    slot.value = out_b.ctypes.data                  # the next replay writes where the slot points NOW
+    assert lib.p2p_replay(arr, n) == 0 and np.array_equal(out_b, want)
+    bad, _ = E.pack_replay([("p2p_png_unfilter", (filt.ctypes.data, h, rb, bpp, slot)), ("p2p_png_unfilter", (None, h, rb, bpp, slot))])
+    assert lib.p2p_replay(bad, 2) != 0
+    msg = lib.p2p_last_error().decode()
+    assert "call 1 of 2" in msg and "p2p_png_unfilter" in msg, msg
+    with pytest.raises(L.P2PError):
+        E.pack_replay([("p2p_png_unfilter", (1, 2, 3))])
+    with pytest.raises(TypeError):
+        E.pack_replay([("p2p_png_unfilter", ("text", h, rb, bpp, slot))])

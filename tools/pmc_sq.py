@@ -12,11 +12,20 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = ["brig_kernel", "igemm_kernel", "wgemm_kernel", "wgrad_small_kernel", "conv_strip_kernel", "conv_fewin_kernel", "conv_fewout_kernel",
-            "norm_act_fwd_vec", "norm_act_bwd_vec", "norm_act_fwd_small", "norm_act_bwd_small", "adam_flat_dev_kernel",
-            "weight_prep_batched_kernel", "act_bwd_vec_kernel", "pack_pair_kernel", "ws_slab_sum_kernel", "rgbuv_hist_fwd_kernel",
-            "rgbuv_hist_bwd_kernel", "softmax256_kernel", "rgbuv_hist_fwd3_kernel", "rgbuv_hist_bwd3_kernel",
-            "rgbuv_points_kernel", "head_softmax_kernel", "head_dgrad_kernel", "adam_prep_batched_kernel"]
+# kernel-name fragments, matched LONGEST FIRST against the demangled or mangled name (r04: "igemm_kernel" is not a substring of
+# "igemm_pipe_kernel" and "wgemm_kernel" is not one of "wgemm_pipe_kernel": the round's two new kernels fell out of the summaries)
+FAMILIES = ["brig_kernel", "igemm_pipe_kernel", "igemm_kernel", "wgemm_pipe_kernel", "wgemm_kernel", "wgrad_small_kernel", "conv_strip_kernel",
+            "conv_fewin_kernel", "conv_fewout_kernel", "norm_act_fwd_vec", "norm_act_bwd_vec", "norm_act_fwd_small", "norm_act_bwd_small",
+            "adam_flat_dev_kernel", "weight_prep_batched_kernel", "act_bwd_vec_kernel", "pack_pair_kernel", "pack_pair_idx_kernel",
+            "ws_slab_sum_kernel", "slab_sum_kernel", "rgbuv_hist_fwd_kernel", "rgbuv_hist_bwd_kernel", "softmax256_kernel",
+            "rgbuv_hist_fwd3_kernel", "rgbuv_hist_bwd3_kernel", "rgbuv_hist_fold_kernel", "hist_grad_prep_kernel", "rgbuv_points_kernel",
+            "head_softmax_kernel", "head_dgrad_kernel", "adam_prep_batched_kernel", "bottleneck_kernel", "view_colsum_px8", "colsum_batched_kernel",
+            "tanh_l1_fwd_pair_kernel", "tanh_l1_bwd_kernel", "bce_logits_kernel", "dropout_mask_kernel"]
+FAMILIES.sort(key=len, reverse=True)
+
+
+def family_of(name):
+    return next((k for k in FAMILIES if k in name), None)
 
 
 def main():
@@ -27,7 +36,7 @@ def main():
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row.get("Kernel_Name", "")
-                fam = next((k for k in FAMILIES if k in name), None)
+                fam = family_of(name)
                 if fam is None:
                     continue
                 acc[fam][row["Counter_Name"]] += float(row["Counter_Value"])
