@@ -130,6 +130,39 @@ def pack_replay(rec):
     return arr, len(rec)
 
 
+class _RecDP:
+    """The data-parallel communicator while a step is being recorded: every collective runs now and is remembered, with the torch
+    stream it was issued under (the backend orders a collective after the work on the CURRENT stream and wait() orders the
+    current stream after the collective).  A replayed step re-issues it between two segments of the recorded call list."""
+
+    def __init__(self, dp):
+        self._dp = dp
+
+    def _remember(self, fn):
+        st = torch.cuda.current_stream()
+
+        def go():
+            with torch.cuda.stream(st):
+                fn()
+        _REC[0].append((None, go))
+
+    def allreduce_async(self, t):
+        self._dp.allreduce_async(t)
+        self._remember(lambda: self._dp.allreduce_async(t))
+
+    def allreduce_scalar_sum(self, t):
+        self._dp.allreduce_scalar_sum(t)
+        self._remember(lambda: self._dp.allreduce_scalar_sum(t))
+        return t
+
+    def wait_all(self):
+        self._dp.wait_all()
+        self._remember(self._dp.wait_all)
+
+    def __getattr__(self, name):
+        return getattr(self._dp, name)
+
+
 # (stream ordering always uses device-only events, p2p_event_*: torch.cuda.Event.record carries a system-scope release that idled
 # the main stream for ~6 us after every fork, r03; the torch fallback and its switch are gone)
 _EVENT_RING, _EVENT_NEXT = [], [0]
@@ -1001,9 +1034,10 @@ class Pix2PixEngine:
     REPLAY_CACHE = 8          # recorded steps kept per engine (least recently used goes first)
 
     def _replay_key(self, kind, B, masks, dp, apply_update, *extra):
-        """key of a replayable step, or None: device RNG masks, single GPU, with the optimizer step, and nobody else
-        instrumenting L.call (bench.py's per-call timing)"""
-        if (masks is not None or dp is not None or not apply_update or B > self.replay_max_batch or self.device.type != "cuda"
+        """key of a replayable step, or None: device RNG masks, with the optimizer step, and nobody else instrumenting L.call
+        (bench.py's per-call timing).  A data-parallel step is replayable too: its collectives are remembered between the
+        segments of the call list (_RecDP); the communicator object is part of the key."""
+        if (masks is not None or not apply_update or B > self.replay_max_batch or self.device.type != "cuda"
                 or L.call is not _ORIG_CALL or not self.replay_enabled or torch.cuda.is_current_stream_capturing()):
             return None
         # everything the recorded calls hold BY VALUE: the switches that choose kernels, the K-split / grid targets and the stream
@@ -1013,7 +1047,8 @@ class Pix2PixEngine:
         st = torch.cuda.current_stream()
         return (kind, B, self.side.enabled, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
                 self.hist_points, self.fuse_act_bwd, self.split_prep, self.full_pixels, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
-                self.use_mfma, int(self.splitk_target), int(self.wgemm_want), int(self.wgemm_want_pipe), int(st.cuda_stream), int(st.stream_id)) + extra
+                self.use_mfma, int(self.splitk_target), int(self.wgemm_want), int(self.wgemm_want_pipe), int(st.cuda_stream), int(st.stream_id),
+                None if dp is None else id(dp)) + extra
 
     def _bind_batch(self, src_t, real_t):
         """the batch tensors of this step behind the re-usable pointer slots the recorded calls hold"""
@@ -1045,19 +1080,35 @@ class Pix2PixEngine:
         rec, _REC[0] = _REC[0], None
         L.call = _ORIG_CALL
         if ok:
-            arr, n = pack_replay(rec)
-            self._replays[key] = (arr, n, rec)          # `rec` keeps every ctypes object alive whose address the records hold
+            # segments: runs of C-ABI calls packed for p2p_replay, separated by the host-side operations of a data-parallel
+            # step (collectives through torch.distributed, _RecDP).  A single-GPU step is one segment.
+            segs, run = [], []
+            for name, args in rec:
+                if name is None:
+                    if run:
+                        segs.append(pack_replay(run))
+                        run = []
+                    segs.append(args)
+                else:
+                    run.append((name, args))
+            if run:
+                segs.append(pack_replay(run))
+            self._replays[key] = (segs, rec)            # `rec` keeps every ctypes object alive whose address the records hold
             while len(self._replays) > self.REPLAY_CACHE:
                 old, _ = self._replays.popitem(last=False)
                 self._replay_seen.pop(old, None)
 
     def _replay(self, key, P, src_t, real_t, hist=False):
-        arr, n, _ = self._replays[key]
+        segs, _ = self._replays[key]
         self._replays.move_to_end(key)
         self._bind_batch(src_t, real_t)
         out = self._new_out()
-        if self._replay_fn(arr, n) != 0:
-            raise L.P2PError(L.lib().p2p_last_error().decode())
+        for seg in segs:
+            if callable(seg):
+                seg()
+            elif self._replay_fn(seg[0], seg[1]) != 0:
+                raise L.P2PError(L.lib().p2p_last_error().decode())
+        self._dp = None
         self.G.t += 1
         self.D.t += 1
         self.step_count += 1
@@ -1198,6 +1249,8 @@ class Pix2PixEngine:
         if key in self._replays:
             return self._replay(key, P, src_t, real_t, hist=lambda_hist is not None)
         recording = self._begin_record(key)
+        if recording and dp is not None:
+            dp = self._dp = _RecDP(dp)
         try:
             out = self._train_step_rgba_body(P, B, Bg, src_t, real_t, lambda_l1, lambda_hist, masks, apply_update, dp)
         except BaseException:
@@ -1545,6 +1598,8 @@ class Pix2PixEngine:
         if key in self._replays:
             return self._replay(key, P, src_t, real_t)
         recording = self._begin_record(key)
+        if recording and dp is not None:
+            self._dp = _RecDP(dp)
         try:
             out = self._train_step_indexed_body(P, B, Bg, src_t, real_t, lambda_segmentation, masks, apply_update)
         except BaseException:

@@ -56,6 +56,17 @@ class ScalarLog:
         if len(self._rows) >= self.max_pending:
             self.flush()
 
+    def image(self, name, sheet, step):
+        """tf.summary.image(name, data, step, max_outputs=5) of ONE uint8 RGBA sheet (side2side_model.py:92-93)"""
+        from . import png
+        self.flush()            # keep the file in step order
+        self.events.add_values([tb_events.encode_image_value(name, [png.encode_png(sheet)], sheet.shape[1], sheet.shape[0])], step)
+
+    def write_raw_pb(self, value, step):
+        """tf.summary.experimental.write_raw_pb of one serialized Summary.Value (side2side_model.py:60-61)"""
+        self.flush()
+        self.events.add_values([value], step)
+
     def flush(self):
         if not self._rows:
             return
@@ -150,6 +161,15 @@ class S2SModel(ABC):
         self.model_name = model_name
         self.architecture_name = architecture_name
         self.checkpoint_dir = os.sep.join([TEMP_FOLDER, "training-checkpoints", self.architecture_name, self.model_name])
+        self.layout_summary = S2SModel.create_layout_summary()
+
+    @staticmethod
+    def create_layout_summary():
+        """side2side_model.py:240-273: the custom-scalar layout (one multiline chart for the FID tags, one for the L1 evaluation
+        tags), as the serialized Summary.Value that fit() writes at step 0"""
+        return tb_events.encode_layout_value(tb_events.encode_layout([
+            ("Fréchet Inception Distance", [("FID for train and test", [r"^fid\/"])]),
+            ("L1 Evaluation", [("L1 for train and test", [r"^l1\-evaluation\/"])])]))
 
     @property
     def is_main_rank(self):
@@ -174,6 +194,7 @@ class S2SModel(ABC):
             self.log_folders = [TEMP_FOLDER, "logs", self.architecture_name, self.model_name]
             self.now_string = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
             self.summary_writer = ScalarLog(os.sep.join([*self.log_folders, self.now_string]))
+            self.summary_writer.write_raw_pb(self.layout_summary, step=0)          # side2side_model.py:59-61
         try:
             self.do_fit(steps, update_steps, callbacks, starting_step)
         finally:
@@ -196,7 +217,13 @@ class S2SModel(ABC):
                 if step != 0:
                     show_eta(training_start_time, step_start_time, step, starting_step, steps, update_steps)
                 step_start_time = time.time()
-                self.preview_generated_images_during_training(examples, None, step + 1)
+                # side2side_model.py:86-93: the sheet goes to <log folder>/step_NNNNNN.png and, under that name, into the event file
+                save_image_name = os.sep.join([TEMP_FOLDER, "logs", self.architecture_name, self.model_name, str(self.now_string),
+                                               "step_{:06d}.png".format(step + 1)])
+                print(f"Previewing images generated at step {step + 1} (3 test + 3 train)...")
+                sheet = self.preview_generated_images_during_training(examples, save_image_name, step + 1)
+                if self.summary_writer is not None:
+                    self.summary_writer.image(save_image_name, sheet, step=(step + 1) // update_steps)
                 if "show_discriminator_output" in callbacks:
                     self.show_discriminated_images("test", 2)          # side2side_model.py:96-97 (numbers instead of plots)
                 if "evaluate_l1" in callbacks:

@@ -207,16 +207,24 @@ def test_world1_rccl_step_matches_plain_step(tmp_path, monkeypatch):
     try:
         batch = _batch("baseline", 4)
         ref = _one_step("baseline", 4, None)
-        m = _make("baseline", None, comm)
-        for step in range(2):
-            g_loss, d_loss = m.train_step(batch, step, 1)
-        torch.cuda.synchronize()
-        m1 = _make("baseline", None, None)
-        for step in range(2):
-            g1, d1 = m1.train_step(batch, step, 1)
-        torch.cuda.synchronize()
-        assert all(float(a) == float(b) for a, b in zip(g_loss + d_loss, g1 + d1))
-        assert torch.equal(m.engine.G.params, m1.engine.G.params) and torch.equal(m.engine.D.params, m1.engine.D.params)
+        # five steps each: with the communicator (steps 3-5 REPLAY the recorded step, the collectives re-issued between the segments
+        # of the call list -- round 5), with the communicator and replay off (every launch from Python), and without a communicator
+        runs = []
+        for dp, replay in ((comm, True), (comm, False), (None, True)):
+            m = _make("baseline", None, dp)
+            m.engine.replay_enabled = replay
+            for step in range(5):
+                g_loss, d_loss = m.train_step(batch, step, 1)
+            torch.cuda.synchronize()
+            runs.append((m, [float(x) for x in g_loss + d_loss]))
+        (m, la), (m2, lb), (m1, lc) = runs
+        assert la == lb == lc
+        for other in (m2, m1):
+            assert torch.equal(m.engine.G.params, other.engine.G.params) and torch.equal(m.engine.D.params, other.engine.D.params)
+            assert torch.equal(m.engine.G.m, other.engine.G.m) and torch.equal(m.engine.G.v, other.engine.G.v)
+        assert len(m.engine._replays) == 1 and len(m2.engine._replays) == 0 and len(m1.engine._replays) == 1
+        segs = next(iter(m.engine._replays.values()))[0]
+        assert sum(1 for sg in segs if callable(sg)) >= len(m.engine.G.buckets) + 1 and len(next(iter(m1.engine._replays.values()))[0]) == 1
         assert np.isfinite(ref[0]).all()
     finally:
         comm.destroy()

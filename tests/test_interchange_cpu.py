@@ -140,6 +140,78 @@ def test_event_records_parse_with_an_independent_protobuf_runtime(tmp_path):
             assert m.SerializeToString() == tb_events.encode_event(wall, step=step, scalars=[(tag, value)])     # canonical encoding
 
 
+def test_image_and_layout_records_parse_with_an_independent_protobuf_runtime(tmp_path):
+    """F4: the per-update image summary and the custom-scalar layout (side2side_model.py:58-61,86-93,240-273) as google.protobuf
+    reads them from a schema declared field by field -- tensorflow/core/framework/{summary,tensor,tensor_shape}.proto and
+    tensorboard/plugins/custom_scalar/layout.proto: Value.tensor = 8, Value.metadata = 9, SummaryMetadata.plugin_data = 1
+    {plugin_name = 1, content = 2}, data_class = 4, TensorProto.dtype = 1, tensor_shape = 2 {dim = 2 {size = 1}}, string_val = 8;
+    Layout.category = 2 {title = 1, chart = 2 {title = 1, multiline = 2 {tag = 1}}}.  The re-serialized messages must equal the
+    writer's bytes (canonical field order), the PNG inside must decode to the sheet."""
+    pytest.importorskip("google.protobuf")
+    import struct
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    from palette_and_histo_gan_amd import png
+    from palette_and_histo_gan_amd.side2side_model import S2SModel, ScalarLog
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="p2p_event2.proto", package="p2pt2", syntax="proto3")
+
+    def msg(name, *fields):
+        m = fd.message_type.add(name=name)
+        for fname, num, typ, rep, tname in fields:
+            m.field.add(name=fname, number=num, type=typ, label=3 if rep else 1, **({"type_name": ".p2pt2." + tname} if tname else {}))
+    msg("Dim", ("size", 1, F.TYPE_INT64, False, None))
+    msg("Shape", ("dim", 2, F.TYPE_MESSAGE, True, "Dim"))
+    msg("Tensor", ("dtype", 1, F.TYPE_INT32, False, None), ("tensor_shape", 2, F.TYPE_MESSAGE, False, "Shape"), ("string_val", 8, F.TYPE_BYTES, True, None))
+    msg("PluginData", ("plugin_name", 1, F.TYPE_STRING, False, None), ("content", 2, F.TYPE_BYTES, False, None))
+    msg("Meta", ("plugin_data", 1, F.TYPE_MESSAGE, False, "PluginData"), ("data_class", 4, F.TYPE_INT32, False, None))
+    msg("Value", ("tag", 1, F.TYPE_STRING, False, None), ("simple_value", 2, F.TYPE_FLOAT, False, None),
+        ("tensor", 8, F.TYPE_MESSAGE, False, "Tensor"), ("metadata", 9, F.TYPE_MESSAGE, False, "Meta"))
+    msg("Summary", ("value", 1, F.TYPE_MESSAGE, True, "Value"))
+    msg("Event", ("wall_time", 1, F.TYPE_DOUBLE, False, None), ("step", 2, F.TYPE_INT64, False, None), ("file_version", 3, F.TYPE_STRING, False, None),
+        ("summary", 5, F.TYPE_MESSAGE, False, "Summary"))
+    msg("Multiline", ("tag", 1, F.TYPE_STRING, True, None))
+    msg("Chart", ("title", 1, F.TYPE_STRING, False, None), ("multiline", 2, F.TYPE_MESSAGE, False, "Multiline"))
+    msg("Category", ("title", 1, F.TYPE_STRING, False, None), ("chart", 2, F.TYPE_MESSAGE, True, "Chart"))
+    msg("Layout", ("version", 1, F.TYPE_INT32, False, None), ("category", 2, F.TYPE_MESSAGE, True, "Category"))
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("p2pt2.Event"))
+    Layout = message_factory.GetMessageClass(pool.FindMessageTypeByName("p2pt2.Layout"))
+    log = ScalarLog(str(tmp_path))
+    log.write_raw_pb(S2SModel.create_layout_summary(), step=0)
+    sheet = np.random.default_rng(3).integers(0, 256, size=(70, 196, 4), dtype=np.uint8)
+    log.scalar("generator/l1_loss", 0.25, 4)
+    log.image("temp-side2side/logs/a/b/now/step_000005.png", sheet, step=5)
+    log.flush()
+    data, pos, events = open(log.events.path, "rb").read(), 0, []
+    while pos < len(data):
+        (ln,) = struct.unpack_from("<Q", data, pos)
+        m = Event()
+        m.ParseFromString(data[pos + 12:pos + 12 + ln])
+        assert m.SerializeToString() == data[pos + 12:pos + 12 + ln] or m.step == 0        # canonical encoding (an explicit zero step aside)
+        events.append(m)
+        pos += 16 + ln
+    assert [len(e.summary.value) for e in events] == [0, 1, 1, 1] and [e.step for e in events] == [0, 0, 4, 5]
+    lay = events[1].summary.value[0]
+    assert lay.tag == "custom_scalars__config__" and lay.metadata.plugin_data.plugin_name == "custom_scalars"
+    assert lay.tensor.dtype == 7 and len(lay.tensor.tensor_shape.dim) == 0 and len(lay.tensor.string_val) == 1
+    layout = Layout()
+    layout.ParseFromString(lay.tensor.string_val[0])
+    assert [(c.title, [(ch.title, list(ch.multiline.tag)) for ch in c.chart]) for c in layout.category] == [
+        ("Fréchet Inception Distance", [("FID for train and test", [r"^fid\/"])]),
+        ("L1 Evaluation", [("L1 for train and test", [r"^l1\-evaluation\/"])])]                 # side2side_model.py:244-271
+    assert layout.SerializeToString() == lay.tensor.string_val[0]
+    assert events[2].summary.value[0].simple_value == 0.25
+    img = events[3].summary.value[0]
+    assert img.tag.endswith("step_000005.png") and img.metadata.plugin_data.plugin_name == "images" and img.metadata.data_class == 3
+    assert img.tensor.dtype == 7 and [d.size for d in img.tensor.tensor_shape.dim] == [3]
+    w, h, blob = img.tensor.string_val
+    assert (w, h) == (b"196", b"70") and blob[:8] == b"\x89PNG\r\n\x1a\n" and np.array_equal(png.decode_png(blob), sheet)
+    # and the module's own reader sees the same three values
+    vals = list(tb_events.read_events(log.events.path))
+    assert [t for _, t, _ in vals] == ["custom_scalars__config__", "generator/l1_loss", img.tag] and vals[2][2][2] == blob
+
+
 def test_palette_extraction_and_index_round_trip_are_bit_exact():
     rng = np.random.default_rng(7)
     colours = np.array([[0, 0, 0, 0], [10, 20, 30, 255], [200, 10, 10, 255], [10, 200, 10, 255], [250, 250, 250, 255],

@@ -1,5 +1,6 @@
 """-m gpu: the reference-API model classes driven like experiments.ipynb drives them, the golden vectors through the
 engine, and the 2-rank data-parallel step (gloo transport, both ranks on the one GPU of the test box)."""
+import json
 import os
 
 import numpy as np
@@ -34,7 +35,19 @@ def test_fit_loop_runs_like_the_notebook(tmp_path, monkeypatch):
     # the same scalars as a TensorBoard event file (what the reference's tf.summary calls leave behind)
     from palette_and_histo_gan_amd import tb_events
     ev = list(tb_events.read_events(model.summary_writer.events.path))
-    assert sum(1 for _, tag, _ in ev if tag == "generator/l1_loss") == 7 and all(np.isfinite(v) for _, _, v in ev)
+    assert sum(1 for _, tag, _ in ev if tag == "generator/l1_loss") == 7 and all(np.isfinite(v) for _, _, v in ev if isinstance(v, float))
+    # F4 (side2side_model.py:58-61,86-93): the custom-scalar layout at step 0, and at step 0 and every update_steps the preview sheet
+    # as <log folder>/step_NNNNNN.png AND as an image summary whose tag is that path, at step (step + 1) // update_steps
+    from palette_and_histo_gan_amd import png
+    folder = os.path.dirname(model.summary_writer.path)
+    assert sorted(f for f in os.listdir(folder) if f.endswith(".png")) == ["step_000001.png", "step_000003.png", "step_000006.png"]
+    assert ev[0][0] == 0 and ev[0][1] == "custom_scalars__config__" and b"l1\\-evaluation" in ev[0][2][0]
+    images = [(st, tag, v) for st, tag, v in ev if isinstance(v, list) and tag.endswith(".png")]
+    assert [st for st, _, _ in images] == [0, 1, 2] and images[1][1].endswith(os.sep.join([model.now_string, "step_000003.png"]))
+    for st, tag, (w, h, data) in images:
+        sheet = png.decode_png(data)
+        assert (int(w), int(h)) == (sheet.shape[1], sheet.shape[0]) == (3 * 64 + 4, 6 * 64 + 10)      # 6 examples x (Input | Target | Generated)
+        assert np.array_equal(sheet, png.read_png(tag))
     # the reference's attribute surface (pix2pix_model.py:12-36)
     assert model.loss_object is not None and model.checkpoint.generator is model.generator
     assert model.generator_optimizer.learning_rate == 0.0002 and model.generator_optimizer.beta_1 == 0.5
@@ -155,22 +168,34 @@ def test_engine_reproduces_golden_vectors():
         for i in range(7):
             assert abs(out[i] - want[i]) <= 1e-4 * abs(want[i]) + 1e-12, (tag, i, out[i], want[i])
         grads = eng.G.export(eng.G.grads)
-        case_dev = max(float(gold[f"{tag}.G.{k}.f32dev"]) for k in grads)
-        case_dev_sum = max(float(gold[f"{tag}.G.{k}.f32dev_abssum"]) for k in grads if np.isfinite(gold[f"{tag}.G.{k}.f32dev_abssum"]))
+        report, failed = {}, []
         for k, a in grads.items():
             a = a.reshape(-1).astype(np.float64)
             samples = gold[f"{tag}.G.{k}.samples"]
             got = a[mg.sample_positions(k, a.size)]
             scale = gold[f"{tag}.G.{k}.abssum"] / a.size + 1e-30
-            # bounds: 2 % of the tensor's scale / 1e-3 of its absolute sum, or 1.5 x what the ORACLE evaluated in float32 does to this
-            # CASE where that is more (histogram case: near-black fake pixels whose gradient is 1 / (x + 1e-6)-steep -- one of them
-            # landing on the other side of a rounding moves every tensor of the step: the f32 oracle is 2.6 % off on up3.kernel's
-            # samples and 1.3e-3 on up4.gamma's sum; which tensors a given f32 evaluation order hits hardest varies, so the
-            # yardstick is the case's worst tensor)
-            tol = max(2e-2, 1.5 * case_dev)
-            assert np.abs(got - samples).max() < tol * max(np.abs(samples).max(), scale), (tag, k)
-            tol_sum = max(1e-3, 1.5 * case_dev_sum)
-            assert abs(np.abs(a).sum() - gold[f"{tag}.G.{k}.abssum"]) <= tol_sum * gold[f"{tag}.G.{k}.abssum"] + 1e-12, (tag, k)
+            # PER-TENSOR bounds: 2 % of the tensor's scale / 1e-3 of its absolute sum, or 1.5 x what the ORACLE evaluated
+            # in float32 does to THIS tensor where that is more (histogram case: near-black fake pixels whose gradient is
+            # 1 / (x + 1e-6)-steep; the f32 oracle is 2.6 % off on up3.kernel's samples and 1.3e-3 on up4.gamma's sum).  A regression
+            # on a well-conditioned tensor can no longer hide under another tensor's ill-conditioning.
+            dev = np.abs(got - samples).max() / max(np.abs(samples).max(), scale)
+            dev_sum = abs(np.abs(a).sum() - gold[f"{tag}.G.{k}.abssum"]) / (gold[f"{tag}.G.{k}.abssum"] + 1e-30)
+            f32dev, f32dev_sum = float(gold[f"{tag}.G.{k}.f32dev"]), float(gold[f"{tag}.G.{k}.f32dev_abssum"])
+            tol = max(2e-2, 1.5 * f32dev)
+            # absolute sums: the yardstick is the LAYER's worst tensor (kernel, gamma and beta gradients of a layer are sums over the
+            # same gradient field d(raw), so one flipped pixel moves all three; measured r05: down2.beta 1.35e-3 with the f32 oracle
+            # at 6.1e-4 on beta and 1.06e-3 on gamma -- profiles/r05_golden_engine_dev.json holds every tensor's figures)
+            layer_sums = [float(gold[f"{tag}.G.{k2}.f32dev_abssum"]) for k2 in grads if k2.split(".")[0] == k.split(".")[0]]
+            layer_dev_sum = max([x for x in layer_sums if np.isfinite(x)] + [0.0])
+            tol_sum = max(1e-3, 1.5 * layer_dev_sum)
+            report[k] = {"dev": float(dev), "f32_oracle_dev": f32dev, "dev_abssum": float(dev_sum), "f32_oracle_dev_abssum": f32dev_sum}
+            if not (dev < tol and (dev_sum <= tol_sum or gold[f"{tag}.G.{k}.abssum"] < 1e-12)):
+                failed.append((k, dev, tol, dev_sum, tol_sum))
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, f"golden_engine_dev_{tag}.json"), "w") as f:       # the engine's measured per-tensor deviation
+            json.dump(report, f, indent=1)
+        assert not failed, (tag, failed)
     # argmax fixture, bit-exact
     p = torch.as_tensor(gold["argmax.probs"]).to("cuda:0")
     out = torch.empty(p.shape[0], dtype=torch.int32, device="cuda:0")
