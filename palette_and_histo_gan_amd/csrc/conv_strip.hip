@@ -250,8 +250,8 @@ extern "C" int p2p_conv_strip(int op, int dtype, int N, int LH, int LW, int Cg, 
     const dim3 grid((unsigned)p.blocks);
     static bool attr_done = false;
     if (!attr_done)
-        attr_done = p2p_allow_lds((const void*)conv_strip_kernel<0>, 160 * 1024, "conv_strip_kernel<0>") &
-                    p2p_allow_lds((const void*)conv_strip_kernel<1>, 160 * 1024, "conv_strip_kernel<1>");
+        attr_done = (int)p2p_allow_lds((const void*)conv_strip_kernel<0>, 160 * 1024, "conv_strip_kernel<0>") &
+                    (int)p2p_allow_lds((const void*)conv_strip_kernel<1>, 160 * 1024, "conv_strip_kernel<1>");
     if (op == P2P_OP_P) conv_strip_kernel<1><<<grid, dim3(CS_THREADS), p.shm, st>>>(a);
     else conv_strip_kernel<0><<<grid, dim3(CS_THREADS), p.shm, st>>>(a);
     return p2p_check_launch("p2p_conv_strip");

@@ -880,8 +880,8 @@ extern "C" int p2p_rgbuv_hist_fwd3(int dtype, int N, int H, int W, const p2p_ten
     constexpr int SHM = H3_SHM;
     static bool attr = false;
     if (!attr)
-        attr = p2p_allow_lds((const void*)rgbuv_hist_fwd3_kernel<float>, SHM, "rgbuv_hist_fwd3_kernel<float>") &
-               p2p_allow_lds((const void*)rgbuv_hist_fwd3_kernel<bf16_t>, SHM, "rgbuv_hist_fwd3_kernel<bf16>");
+        attr = (int)p2p_allow_lds((const void*)rgbuv_hist_fwd3_kernel<float>, SHM, "rgbuv_hist_fwd3_kernel<float>") &
+               (int)p2p_allow_lds((const void*)rgbuv_hist_fwd3_kernel<bf16_t>, SHM, "rgbuv_hist_fwd3_kernel<bf16>");
     P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd3_kernel<T><<<dim3(N, H3_PS), H3_NT, SHM, st>>>(H, W, make_view(img), (const f32x4*)points,
                                                                                             npoints, cap, workspace)));
     int rc = p2p_check_launch("p2p_rgbuv_hist_fwd3");
@@ -920,8 +920,8 @@ extern "C" int p2p_rgbuv_hist_hellinger_bwd3(int dtype, int N, int H, int W, con
     static_assert(SHM <= 160 * 1024, "rgbuv_hist_bwd3_kernel: LDS");
     static bool attr = false;
     if (!attr)
-        attr = p2p_allow_lds((const void*)rgbuv_hist_bwd3_kernel<float>, SHM, "rgbuv_hist_bwd3_kernel<float>") &
-               p2p_allow_lds((const void*)rgbuv_hist_bwd3_kernel<bf16_t>, SHM, "rgbuv_hist_bwd3_kernel<bf16>");
+        attr = (int)p2p_allow_lds((const void*)rgbuv_hist_bwd3_kernel<float>, SHM, "rgbuv_hist_bwd3_kernel<float>") &
+               (int)p2p_allow_lds((const void*)rgbuv_hist_bwd3_kernel<bf16_t>, SHM, "rgbuv_hist_bwd3_kernel<bf16>");
     P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_bwd3_kernel<T><<<dim3(N, nsplit), B3_NT, SHM, st>>>(H, W, make_view(fake), gh_ws, dimg, nsplit)));
     return p2p_check_launch("p2p_rgbuv_hist_hellinger_bwd3");
 }

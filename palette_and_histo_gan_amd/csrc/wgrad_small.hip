@@ -426,8 +426,8 @@ static int ws_launch(WsArgs& a, int stride, const WsPlan& p, hipStream_t st) {
     do {                                                                                                               \
         static bool done = false;                                                                                      \
         if (!done)                                                                                                     \
-            done = p2p_allow_lds((const void*)wgrad_small_kernel<T, S_, G_, D_, 2>, 160 * 1024, "wgrad_small_kernel") &   \
-                   p2p_allow_lds((const void*)wgrad_small_kernel<T, S_, G_, D_, 1>, 160 * 1024, "wgrad_small_kernel");    \
+            done = (int)p2p_allow_lds((const void*)wgrad_small_kernel<T, S_, G_, D_, 2>, 160 * 1024, "wgrad_small_kernel") &   \
+                   (int)p2p_allow_lds((const void*)wgrad_small_kernel<T, S_, G_, D_, 1>, 160 * 1024, "wgrad_small_kernel");    \
         if (ws_waves16() && !p.pack) wgrad_small_kernel<T, S_, G_, D_, 1><<<grid, dim3(1024), p.shm, st>>>(a);         \
         else wgrad_small_kernel<T, S_, G_, D_, 2><<<grid, dim3(512), p.shm, st>>>(a);                                  \
     } while (0)
