@@ -103,8 +103,8 @@ def kernel_profile(eng, run_step, n_steps=3):
         a.record()
         orig(name, *args)
         b.record()
-        # the fused blocks (convolution + InstanceNorm + activation in one launch) are the same kernel family as p2p_igemm
-        records.append(("p2p_igemm" if name in ("p2p_igemm_norm_act", "p2p_igemm_norm_small") else name, args, a, b))
+        # the fused block (convolution + InstanceNorm + activation) is the same kernel family as p2p_igemm, which dispatches to it
+        records.append(("p2p_igemm" if name == "p2p_igemm_norm_act" else name, args, a, b))
 
     L.call = timed
     E.L.call = timed

@@ -109,20 +109,6 @@ int p2p_igemm_norm_act(int op, int dtype, int N, int LH, int LW, int Cg, int Cd,
                        const void* w, const float* gamma, const float* beta, float eps, int act, float alpha,
                        const p2p_tensor* act_out, float* stats, void* stream);
 int p2p_brig_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
-/* The same block (networks.py:7-21 / 24-36, WITH its dropout) in one launch on the small maps of the U-Net bottom -- output maps
- * of at most 16 pixels: down4..down6, up1, up2 at 64x64 sprites -- where the convolution is split over K to fill the chip and a
- * workgroup cannot see a whole image's sum: p2p_igemm with `splitk` (f32 partial slabs as there; splitk == 1 writes `raw_out`
- * directly and `lo`/`hi` must be that tensor), after which the workgroup that finishes LAST among those that contribute to a
- * group of images (all K splits and sub-pixel phases of a pixel tile x column tile, counted in `tickets`) sums the slabs in slab
- * order and applies p2p_norm_act_fwd to those images: raw_out (dense, `dtype`), stats[N][Cout][2] = (mean, rstd), and
- * act(drop(gamma (x - mean) rstd + beta)) into the view act_out; `mask` = dropout keep-mask (u8, dense) or null.  Same arithmetic
- * in the same order as the two launches: bit-identical results.  tickets: 4096 ints, zero before the first call; every call leaves
- * them zero.  p2p_igemm_norm_small_ok tells whether the shape qualifies (environment P2P_NORM_TAIL=0: never). */
-int p2p_igemm_norm_small_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, int splitk);
-int p2p_igemm_norm_small(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
-                         const void* w, int splitk, float* slabs, const float* gamma, const float* beta, float eps, int act,
-                         float alpha, const unsigned char* mask, const p2p_tensor* act_out, void* raw_out, float* stats,
-                         int* tickets, void* stream);
 int p2p_igemm_layer_stat_slots(int op, int dtype, int N, int LH, int LW, int Cg, int Cd);
 
 /* Edge-layer form of the same kernel (Cin 1..8, the 36/33-channel concat, Cout 1..4; networks.py:46-48,57,75-78):

@@ -31,7 +31,6 @@ SIGNATURES = {
     "p2p_conv_direct": [_i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp, _vp, _vp],
     "p2p_igemm": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp, _vp],
     "p2p_igemm_norm_act": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp, _f, _i, _f, _TP, _vp, _vp],
-    "p2p_igemm_norm_small": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _i, _vp, _vp, _vp, _f, _i, _f, _vp, _TP, _vp, _vp, _vp, _vp],
     "p2p_igemm_edge": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
     "p2p_conv_strip": [_i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _vp],
     "p2p_conv_fewin": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _TP, _TP, _vp, _vp, _i, _f, _vp],
@@ -102,7 +101,6 @@ SPECIAL = {"p2p_last_error": ([], C.c_char_p),
            "p2p_brig_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_igemm_norm_act_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_brig_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
-           "p2p_igemm_norm_small_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_igemm_layer_stat_slots": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_fewin_ok": ([_i, _i, _i, _i, _i, _i, _i, _i], C.c_int),
            "p2p_conv_strip_ok": ([_i, _i, _i, _i, _i, _i, _i], C.c_int),

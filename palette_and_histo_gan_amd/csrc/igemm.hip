@@ -19,7 +19,6 @@
 // GEN = true : any multiple of 16 bytes per tap (edge layers: 8-channel images, the 36(+4)-channel concat, the
 //              33(+7)-channel indexed concat), plus bias / LeakyReLU / column mask in the epilogue.
 #include "p2p_common.hpp"
-#include "norm_small.hpp"
 #include <stdlib.h>
 #include <utility>
 
@@ -53,16 +52,6 @@ struct IgemmArgs {
     // fused InstanceNorm statistics (VEPI epilogue): per (image, slot, channel) the mean and the centred sum of squares
     // of `stat_rows` consecutive output pixels of one image; slot = phase * tiles_per_image + tile_in_image
     float* stat_part; int stat_rows; int stat_slots; int lgHW;
-    // InstanceNorm + dropout + activation of the small maps in the SAME launch (p2p_igemm_norm_small): the workgroup that arrives
-    // last at the ticket of its (pixel tile, column tile) -- after every K split and sub-pixel phase of that tile has stored its
-    // part -- normalises the tile's images.  nt_tickets == nullptr: off.
-    int* nt_tickets;
-    const float* nt_gamma; const float* nt_beta; float nt_eps; int nt_act; float nt_alpha;
-    const unsigned char* nt_mask;
-    TView nt_out;                  // activation output (haloed, channel-sliced view)
-    void* nt_raw_out;              // dense raw tensor in T (split-K: written here; splitk == 1: the convolution already wrote it)
-    float* nt_stats;
-    int nt_HW, nt_W, nt_lgG;       // output map of the layer, lane-group size of norm_fwd_small_item
 };
 
 template <typename T> struct Frag;
@@ -702,40 +691,6 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void igemm_pipe_kernel(IgemmArgs
         }
     }
     igemm_epilogue<T, false, VEPI, BM, BN, NTHR, TM, TN, KG>(a, acc, smem, tid, lane, h, wm, wn, kg, m0, n0, ks, phase);
-
-    // ---- small maps: the last workgroup of a (pixel tile, column tile) normalises the tile's images -----------------------------------
-    // Every workgroup publishes its stores (release at device scope: the slabs of other workgroups live in other XCDs' L2s), takes a
-    // ticket, and the one that draws the last ticket -- every K split and sub-pixel phase of the tile has stored its part by then --
-    // acquires and runs p2p_norm_act_fwd's lane-group code over the tile's images: the same arithmetic in the same slab order as the
-    // separate launch, bit for bit.  No workgroup waits for another one (no spinning), so the scheme cannot hang.
-    if (a.nt_tickets) {
-        int* const s_last = (int*)smem;               // (the kernel's LDS is all dynamic and the attribute above allows exactly 160 KB of it:
-        __threadfence();                              // the flag lives in the epilogue's staging area, which nobody reads behind this barrier)
-        __syncthreads();
-        if (tid == 0) {
-            int* tk = a.nt_tickets + (bx * (int)gridDim.y + by);
-            const int t = atomicAdd(tk, 1);
-            *s_last = t == (int)gridDim.z - 1;
-            if (*s_last) *tk = 0;                      // everybody has arrived: ready for the next launch
-        }
-        __syncthreads();
-        if (*s_last) {
-            __threadfence();
-            constexpr int VN = VecOf<T>::N;
-            const int img0 = m0 >> a.lgHW;
-            const int rows = min(a.M - m0, BM);
-            const int nimg = rows >> a.lgHW;
-            const int cvn = min(BN, a.ncols - n0) / VN;
-            const int threads = (nimg * cvn) << a.nt_lgG;
-            for (int gid = tid; gid < threads; gid += NTHR) {         // whole lane groups stay together: 2^lgG divides 64 and NTHR
-                const int item = gid >> a.nt_lgG, g = gid & ((1 << a.nt_lgG) - 1);
-                const int n = img0 + item / cvn, c = n0 + (item % cvn) * VN;
-                norm_fwd_small_item<T, 1>(n, c, g, a.nt_HW, a.nt_W, a.ncols, a.nt_lgG, a.splitk > 1 ? (const void*)a.slabs : (const void*)a.nt_raw_out,
-                                          a.splitk > 1 ? 2 : 1, a.splitk, a.slab_stride, a.nt_gamma, a.nt_beta, a.nt_eps, a.nt_act, a.nt_alpha,
-                                          a.nt_mask, a.nt_out, a.splitk > 1 ? (T*)a.nt_raw_out : (T*)nullptr, a.nt_stats);
-            }
-        }
-    }
 }
 
 static int ilog2_exact(long long v) {
@@ -845,7 +800,6 @@ static int igemm_launch(IgemmArgs& a, int phases, bool vepi, hipStream_t st) {
             if (ok) return p2p_check_launch("p2p_igemm");
         }
     }
-    P2P_REQUIRE(!a.nt_tickets, "p2p_igemm_norm_small: the shape is not served by the pipelined kernel (query p2p_igemm_norm_small_ok)");
     if (igemm_bm(a.M, ctiles, gz) == 256 && ctiles % 128 == 0) igemm_go<T, 4, 2, 2, 2, GEN>(a, gz, vepi, st);
     // 128x128: eight waves (32x64 each), i.e. twice the waves per SIMD for the same LDS: +12 % over four 64x64 waves
     // (r01, A/B on one device); the 64- and 32-column tiles measured no better with eight waves and keep four
@@ -864,15 +818,9 @@ extern "C" int p2p_igemm_stat_slots(int op, int N, int LH, int LW, int ncols);
 
 // Shared implementation.  C = channels of the gathered operand as laid out in `w` and read from the input
 // view (whole 16-byte chunks), w_rows = rows per weight tap slab (multiple of 32, >= the launched columns).
-struct IgemmNormTail {      // arguments of p2p_igemm_norm_small beyond p2p_igemm's
-    int* tickets; const float* gamma; const float* beta; float eps; int act; float alpha;
-    const unsigned char* mask; const p2p_tensor* act_out; void* raw_out; float* stats;
-};
-#define P2P_NORM_TICKETS 4096          // ints behind `tickets` (one per pixel tile x column tile of a launch)
-
 static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, int C, int ncols, int w_rows,
                         const p2p_tensor* in, const p2p_tensor* out, const void* w, const float* bias, int act,
-                        float alpha, int splitk, float* slabs, float* stat_part, void* stream, const IgemmNormTail* nt = nullptr) {
+                        float alpha, int splitk, float* slabs, float* stat_part, void* stream) {
     const int esz = dtype == P2P_BF16 ? 2 : 4;
     IgemmArgs a;
     a.C = C; a.ncols = ncols; a.w_rows = w_rows;
@@ -939,24 +887,6 @@ static int igemm_common(int op, int stride, int dtype, int N, int LH, int LW, in
         a.stat_rows = hw < bm ? hw : bm;
         a.stat_slots = slots;
     }
-    a.nt_tickets = nullptr;
-    if (nt) {
-        const int hw_out = (a.mode == 1 ? 4 : 1) * LH * LW;
-        const int vn = 16 / esz;
-        P2P_REQUIRE(pow2 && vepi && hw_out <= 16 && stride == 2, "p2p_igemm_norm_small: output maps of at most 16 pixels of a stride-2 block");
-        P2P_REQUIRE(nt->tickets && nt->act_out && nt->act_out->ptr && nt->raw_out && nt->gamma && nt->beta && nt->stats,
-                    "p2p_igemm_norm_small: null pointer");
-        P2P_REQUIRE(ncols % 128 == 0 && nt->act_out->ld % vn == 0 && ((uintptr_t)nt->act_out->ptr % 16) == 0 && ((uintptr_t)nt->raw_out % 16) == 0,
-                    "p2p_igemm_norm_small: whole 128-column tiles of 16-byte vectors");
-        P2P_REQUIRE((long long)((a.M + 127) / 128) * (ncols / 128) <= P2P_NORM_TICKETS, "p2p_igemm_norm_small: more than %d tiles", P2P_NORM_TICKETS);
-        P2P_REQUIRE(splitk > 1 || out->ptr == nt->raw_out, "p2p_igemm_norm_small: with splitk == 1 the convolution writes the raw tensor");
-        a.nt_tickets = nt->tickets;
-        a.nt_gamma = nt->gamma; a.nt_beta = nt->beta; a.nt_eps = nt->eps; a.nt_act = nt->act; a.nt_alpha = nt->alpha;
-        a.nt_mask = nt->mask; a.nt_out = make_view(nt->act_out); a.nt_raw_out = nt->raw_out; a.nt_stats = nt->stats;
-        a.nt_HW = hw_out; a.nt_W = (a.mode == 1 ? 2 : 1) * LW;
-        int ppl;
-        small_geom(hw_out, a.nt_lgG, ppl);
-    }
     if (pow2) { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, false>(a, phases, vepi, st))); }
     else { P2P_DISPATCH_DTYPE(dtype, return (igemm_launch<T, true>(a, phases, vepi, st))); }
 }
@@ -1002,39 +932,6 @@ extern "C" int p2p_igemm(int op, int dtype, int N, int LH, int LW, int Cg, int C
     const p2p_tensor* out = op == P2P_OP_G ? lo : hi;
     const int C = op == P2P_OP_G ? Cg : Cd, ncols = op == P2P_OP_G ? Cd : Cg;
     return igemm_common(op, 2, dtype, N, LH, LW, C, ncols, ncols, in, out, w, nullptr, P2P_ACT_NONE, 0.f, splitk, slabs, stat_part, stream);
-}
-
-// Small maps: convolution + InstanceNorm + dropout + activation in one launch (see the tail of igemm_pipe_kernel).
-extern "C" int p2p_igemm_norm_small_ok(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, int splitk) {
-    if (!(op == P2P_OP_G || op == P2P_OP_P) || !(dtype == P2P_F32 || dtype == P2P_BF16) || N <= 0 || LH <= 0 || LW <= 0) return 0;
-    if (Cg <= 0 || Cd <= 0 || Cg % 32 || Cd % 32 || splitk < 1) return 0;
-    static int on = -1;
-    if (on < 0) on = igemm_env("P2P_NORM_TAIL", 1);
-    if (!on || !igemm_pipe_mode()) return 0;
-    const int esz = dtype == P2P_BF16 ? 2 : 4;
-    const int C = op == P2P_OP_G ? Cg : Cd, ncols = op == P2P_OP_G ? Cd : Cg;
-    if ((op == P2P_OP_P ? 4 : 1) * LH * LW > 16) return 0;                       // output map of at most 16 pixels
-    if (ilog2_exact(LH) < 0 || ilog2_exact(LW) < 0 || ilog2_exact((long long)C * esz) < 7 || ncols % 128) return 0;
-    const int live = (LH == 1 && LW == 1) ? 1 : 0;
-    const int ntaps = live ? (op == P2P_OP_P ? 1 : 4) : (op == P2P_OP_P ? 4 : 16);
-    if (ntaps % splitk || ((long long)(ntaps / splitk) * C * esz) % 128) return 0;
-    if ((long long)(((long long)N * LH * LW + 127) / 128) * (ncols / 128) > P2P_NORM_TICKETS) return 0;
-    if (splitk == 1 && p2p_brig_ok(op, dtype, N, LH, LW, Cg, Cd)) return 0;       // (never for maps this small; p2p_igemm would divert)
-    return 1;
-}
-
-extern "C" int p2p_igemm_norm_small(int op, int dtype, int N, int LH, int LW, int Cg, int Cd, const p2p_tensor* hi, const p2p_tensor* lo,
-                                    const void* w, int splitk, float* slabs, const float* gamma, const float* beta, float eps, int act,
-                                    float alpha, const unsigned char* mask, const p2p_tensor* act_out, void* raw_out, float* stats,
-                                    int* tickets, void* stream) {
-    P2P_REQUIRE(p2p_igemm_norm_small_ok(op, dtype, N, LH, LW, Cg, Cd, splitk), "p2p_igemm_norm_small: shape not supported (op %d, %dx%d, %d -> %d, splitk %d)",
-                op, LH, LW, Cg, Cd, splitk);
-    P2P_REQUIRE(hi && lo && hi->ptr && lo->ptr && w, "p2p_igemm_norm_small: null pointer");
-    const p2p_tensor* in = op == P2P_OP_G ? hi : lo;
-    const p2p_tensor* out = op == P2P_OP_G ? lo : hi;
-    const int C = op == P2P_OP_G ? Cg : Cd, ncols = op == P2P_OP_G ? Cd : Cg;
-    const IgemmNormTail nt = {tickets, gamma, beta, eps, act, alpha, mask, act_out, raw_out, stats};
-    return igemm_common(op, 2, dtype, N, LH, LW, C, ncols, ncols, in, out, w, nullptr, P2P_ACT_NONE, 0.f, splitk, slabs, nullptr, stream, &nt);
 }
 
 extern "C" int p2p_igemm_edge(int op, int stride, int dtype, int N, int LH, int LW, int cin_pad, int ncols,

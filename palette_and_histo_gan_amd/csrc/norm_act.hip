@@ -3,7 +3,6 @@
 // Concatenate at networks.py:18-19,29-34,94; backward = the tape gradient of that chain, closed form in
 // SURVEY.md 8a A13 (checked against autograd in tests/test_oracle.py).
 #include "p2p_common.hpp"
-#include "norm_small.hpp"
 #include <stdlib.h>
 
 typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
@@ -161,6 +160,42 @@ __global__ void norm_act_bwd_kernel(int H, int W, int C, int CB, const T* __rest
 // wave reads whole 128-byte pixel segments.  Pass 1 reduces per channel over the image (shifted sums: the
 // first pixel's value is subtracted before squaring, so E[x^2]-E[x]^2 does not cancel), pass 2 re-reads the
 // image (L2-resident: <= 512 KB per workgroup) and writes the result.
+template <typename T> struct VecOf;
+template <> struct VecOf<bf16_t> { static constexpr int N = 8; typedef bf16x8 type; };
+template <> struct VecOf<float> { static constexpr int N = 4; typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ void vload(const T* p, float* v) {
+    typename VecOf<T>::type r = *(const typename VecOf<T>::type*)p;
+#pragma unroll
+    for (int k = 0; k < VecOf<T>::N; ++k) v[k] = to_f32((T)r[k]);
+}
+template <typename T>
+__device__ __forceinline__ void vstore(T* p, const float* v) {
+    typename VecOf<T>::type r;
+#pragma unroll
+    for (int k = 0; k < VecOf<T>::N; ++k) r[k] = from_f32<T>(v[k]);
+    *(typename VecOf<T>::type*)p = r;
+}
+
+template <typename T>
+__device__ __forceinline__ void raw_vload(const void* raw, int raw_kind, int nslabs, long long slab, long long e, float* v) {
+    constexpr int VN = VecOf<T>::N;
+    if (raw_kind == 1) { vload<T>((const T*)raw + e, v); return; }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) v[k] = 0.f;
+    const float* p = (const float*)raw + e;
+    for (int sIdx = 0; sIdx < nslabs; ++sIdx) {
+#pragma unroll
+        for (int k = 0; k < VN; k += 4) {
+            f32x4 r = *(const f32x4*)(p + (long long)sIdx * slab + k);
+            v[k] += r[0]; v[k + 1] += r[1]; v[k + 2] += r[2]; v[k + 3] += r[3];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) v[k] = to_f32(from_f32<T>(v[k]));
+}
+
 template <typename T>
 __device__ __forceinline__ void gsrc_vload(const GSrc& g, long long pix, int c, float* v) {
     constexpr int VN = VecOf<T>::N;
@@ -177,6 +212,18 @@ __device__ __forceinline__ void gsrc_vload(const GSrc& g, long long pix, int c, 
     for (int sIdx = 0; sIdx < g.nslabs; ++sIdx)
 #pragma unroll
         for (int k = 0; k < VN; ++k) v[k] += p[(long long)sIdx * g.slab + k];
+}
+
+__device__ __forceinline__ void mask_vload8(const unsigned char* m, float* keep, int VN) {
+    if (VN == 8) {
+        unsigned long long r = *(const unsigned long long*)m;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) keep[k] = ((r >> (8 * k)) & 0xff) ? 2.f : 0.f;
+    } else {
+        unsigned r = *(const unsigned*)m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) keep[k] = ((r >> (8 * k)) & 0xff) ? 2.f : 0.f;
+    }
 }
 
 // Column totals of two per-thread partial vectors over the PR pixel rows of a 256-thread workgroup (fixed order, so
@@ -517,7 +564,59 @@ __global__ __launch_bounds__(256) void norm_act_fwd_small(int HW, int W, int C, 
     if (item >= items) return;                       // whole lane groups leave together (G divides 64)
     const int cvn = C / VN;
     const int n = (int)(item / cvn), c = (int)(item - (long long)n * cvn) * VN;
-    norm_fwd_small_item<T, PPL>(n, c, g, HW, W, C, lgG, raw, raw_kind, nslabs, slab, gamma, beta, eps, act, alpha, mask, out, raw_out, stats);
+    const long long base = (long long)n * HW * C + c;
+    float x[PPL][VN];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = g + i * G;
+        if (p < HW) raw_vload<T>(raw, raw_kind, nslabs, slab, base + (long long)p * C, x[i]);
+        else {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) x[i][k] = 0.f;
+        }
+    }
+    float mu[VN], rs[VN];
+    if (gamma) {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) s += x[i][k];               // absent pixels hold 0
+            for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            mu[k] = s / (float)HW;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                const float d = (g + i * G < HW) ? x[i][k] - mu[k] : 0.f;
+                q += d * d;
+            }
+            for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            rs[k] = rsqrtf(q / (float)HW + eps);
+            if (g == 0) {
+                stats[((long long)n * C + c + k) * 2 + 0] = mu[k];
+                stats[((long long)n * C + c + k) * 2 + 1] = rs[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = g + i * G;
+        if (p >= HW) continue;
+        const long long e = base + (long long)p * C;
+        float keep[VN], y[VN];
+        if (raw_out) vstore<T>(raw_out + e, x[i]);
+        if (mask) mask_vload8(mask + e, keep, VN);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float v = gamma ? (x[i][k] - mu[k]) * rs[k] * gamma[c + k] + beta[c + k] : x[i][k];
+            if (mask) v *= keep[k];
+            if (act == P2P_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+            else if (act == P2P_ACT_RELU) v = v > 0.f ? v : 0.f;
+            y[k] = v;
+        }
+        const int yy = p / W, xx = p - yy * W;
+        vstore<T>((T*)out.ptr + out.off(n, yy, xx) + c, y);
+    }
 }
 
 template <typename T, int PPL>
@@ -594,6 +693,15 @@ __global__ __launch_bounds__(256) void norm_act_bwd_small(int HW, int W, int C, 
         const int yy = p / W, xx = p - yy * W;
         vstore<T>((T*)draw.ptr + draw.off(n, yy, xx) + c, r);
     }
+}
+
+// lane-group geometry of the small-map kernels: G = 2^lgG lanes per item, PPL pixels per lane
+static inline void small_geom(int HW, int& lgG, int& ppl) {
+    lgG = 0;
+    while ((1 << lgG) < HW && lgG < 4) ++lgG;
+    const int G = 1 << lgG;
+    const int need = (HW + G - 1) / G;
+    ppl = need <= 1 ? 1 : (need <= 2 ? 2 : 4);
 }
 
 // Batched column sums: task t reduces part[off_t .. off_t + rows*cols) (dense [rows][cols]) over rows into

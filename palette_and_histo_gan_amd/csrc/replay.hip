@@ -44,7 +44,7 @@ struct Entry {
 #define P2P_E(f) {#f, &Thunk<&f>::call, arg_count(&f)},
 // every entry point of p2pgan.h that returns int (tests/test_host_cpu.py checks the list against the header)
 constexpr Entry TABLE[] = {
-    P2P_E(p2p_conv_direct) P2P_E(p2p_igemm) P2P_E(p2p_igemm_norm_act) P2P_E(p2p_igemm_norm_small)
+    P2P_E(p2p_conv_direct) P2P_E(p2p_igemm) P2P_E(p2p_igemm_norm_act)
     P2P_E(p2p_igemm_edge) P2P_E(p2p_conv_strip) P2P_E(p2p_conv_fewin)
     P2P_E(p2p_conv_fewin_actbwd) P2P_E(p2p_conv_fewout) P2P_E(p2p_wgemm_edge)
     P2P_E(p2p_wgrad_small) P2P_E(p2p_view_colsum) P2P_E(p2p_act_bwd)

@@ -494,9 +494,6 @@ class Pix2PixEngine:
         self.replay_enabled = os.environ.get("P2P_REPLAY", "1") != "0"
         self._slot_src, self._slot_real, self._slot_out = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._real_view = L.Tensor(None, 0, 0, 4)
-        # small maps (output of <= 16 pixels): convolution + InstanceNorm + dropout + activation in one launch, the convolution's last
-        # workgroup per tile normalises (p2p_igemm_norm_small; 0: two launches, bit-identical results)
-        self.use_norm_tail = os.environ.get("P2P_NORM_TAIL", "1") != "0"
         self.use_head_fused = os.environ.get("P2P_HEAD_FUSED", "1") != "0"    # indexed head: conv + softmax + CCE + argmax + gradient in one launch
         # histogram loss: three shared kernel rows per pixel with all components in one workgroup (forward and backward), the real
         # image contracted over its distinct colours.  The per-component kernels remain in the library as cross-checks
@@ -744,7 +741,6 @@ class Pix2PixEngine:
         P["g_dcat"] = DenseBuf(B, S, S, 4 if (self.in_ch == 4 and self.full_pixels) else self.dcat_ch, tdt, dev)
         if not self.use_mfma:
             P["d_raw"] = DenseBuf(2 * B, h2, h2, 64, tdt, dev)
-        P["tickets"] = torch.zeros(4096, dtype=torch.int32, device=dev)       # p2p_igemm_norm_small: arrival counts per tile, left zero by every launch
         P["nws"] = torch.empty(max(B, 2) * 16 * 1024 * 2, dtype=torch.float32, device=dev)   # norm split partials [N][16][C<=1024][2]
         P["spart"] = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=dev)    # conv-epilogue statistics [N][slots][C][2]
         # split-K / wgrad workspaces
@@ -894,26 +890,6 @@ class Pix2PixEngine:
         w = _p(lw.wt) if op == L.OP_G else self._wn("G", name)
         L.call("p2p_igemm_norm_act", op, self.dtype, N, lh, lh, lw.cg, lw.cd, C.byref(hi), C.byref(lo), w,
                self.G.p(name + ".gamma"), self.G.p(name + ".beta"), IN_EPS, act, LEAKY_ALPHA, C.byref(out_view), _p(stats), _stream())
-        return True
-
-    def _small_block(self, P, op, name, N, lh, in_view, raw_buf, act, mask, out_view, stats):
-        """Convolution + InstanceNorm + dropout + activation of a generator block whose OUTPUT map has at most 16 pixels (down4-6,
-        up1, up2 at 64x64 sprites) in one launch: p2p_igemm's K split stays, the last workgroup of a tile normalises
-        (p2p_igemm_norm_small).  Returns False where the shape does not qualify (the caller issues the two launches)."""
-        lw = self.W[("G", name)]
-        if not (self.use_mfma and self.use_norm_tail and lw.main):
-            return False
-        sk = self._splitk(op, N, lh, lw.cg, lw.cd)
-        if not L.lib().p2p_igemm_norm_small_ok(op, self.dtype, N, lh, lh, lw.cg, lw.cd, sk):
-            return False
-        out_ch = lw.cd if op == L.OP_G else lw.cg
-        if sk > 1 and sk * raw_buf.n * raw_buf.h * raw_buf.w * out_ch > P["slabs"].numel():
-            return False
-        hi, lo = (in_view, raw_buf.view()) if op == L.OP_G else (raw_buf.view(), in_view)
-        w = _p(lw.wt) if op == L.OP_G else self._wn("G", name)
-        L.call("p2p_igemm_norm_small", op, self.dtype, N, lh, lh, lw.cg, lw.cd, C.byref(hi), C.byref(lo), w, sk,
-               _p(P["slabs"]) if sk > 1 else NULL, self.G.p(name + ".gamma"), self.G.p(name + ".beta"), IN_EPS, act, LEAKY_ALPHA,
-               _p(mask) if mask is not None else NULL, C.byref(out_view), raw_buf.ptr(), _p(stats), _p(P["tickets"]), _stream())
         return True
 
     def _c6_tail(self, P):
@@ -1070,7 +1046,7 @@ class Pix2PixEngine:
         # part of the key: the records hold the address of their slots (_slot_lr ...), one recording serves every value.
         st = torch.cuda.current_stream()
         return (kind, B, self.side.enabled, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
-                self.hist_points, self.fuse_act_bwd, self.split_prep, self.full_pixels, self.use_norm_tail, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
+                self.hist_points, self.fuse_act_bwd, self.split_prep, self.full_pixels, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
                 self.use_mfma, int(self.splitk_target), int(self.wgemm_want), int(self.wgemm_want_pipe), int(st.cuda_stream), int(st.stream_id),
                 None if dp is None else id(dp)) + extra
 
@@ -1188,8 +1164,6 @@ class Pix2PixEngine:
                 self._conv(P, L.OP_G, "G", "down1", B, res, src_view, out_view, act=L.ACT_LEAKY, tmp=P["rd"].get(1))
             elif self._fused_block(P, L.OP_G, f"down{i}", B, res, src_view, P["rd"][i], L.ACT_LEAKY, out_view, P["sd"][i]):
                 pass
-            elif self._small_block(P, L.OP_G, f"down{i}", B, res, src_view, P["rd"][i], L.ACT_LEAKY, None, out_view, P["sd"][i]):
-                pass
             else:
                 rk = self._conv(P, L.OP_G, "G", f"down{i}", B, res, src_view, P["rd"][i].view(), want_stats=True)
                 self._norm_fwd(P, B, res, f, P["rd"][i], rk, self.G.p(f"down{i}.gamma"), self.G.p(f"down{i}.beta"),
@@ -1203,6 +1177,7 @@ class Pix2PixEngine:
                                                            c[i].view(coff=0), P["su"][i]):
                 lo_view = c[i].view()
                 continue
+            rk = self._conv(P, L.OP_P, "G", f"up{i}", B, lh, lo_view, P["ru"][i].view(), want_stats=True)
             mask = None
             if UP_DROPOUT[i - 1]:
                 mask = P["mask"][i]
@@ -1215,10 +1190,6 @@ class Pix2PixEngine:
                 else:       # Bernoulli(0.5) keep mask (networks.py:31-32), counter-based device RNG
                     L.call("p2p_dropout_mask_dev", _p(mask), mask.numel(), self._slot_seed, _p(self.mask_counter_dev), i,
                            self._batch_offset * (mask.numel() // B), _stream())
-            if self._small_block(P, L.OP_P, f"up{i}", B, lh, lo_view, P["ru"][i], L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i]):
-                lo_view = c[i].view()
-                continue
-            rk = self._conv(P, L.OP_P, "G", f"up{i}", B, lh, lo_view, P["ru"][i].view(), want_stats=True)
             self._norm_fwd(P, B, 2 * lh, f, P["ru"][i], rk, self.G.p(f"up{i}.gamma"), self.G.p(f"up{i}.beta"),
                            L.ACT_RELU, mask, c[i].view(coff=0), P["su"][i],
                            tail=P["src"].view() if i == 6 and self._c6_tail(P) else None)

@@ -70,11 +70,11 @@ def call_work(name, args, dtype):
        or None for calls that move a few KB (loss finishing, counters)."""
     esz = 2 if dtype == "bf16" else 4
     mf = dtype
-    if name in ("p2p_igemm", "p2p_igemm_norm_act", "p2p_igemm_norm_small", "p2p_conv_strip"):
+    if name in ("p2p_igemm", "p2p_igemm_norm_act", "p2p_conv_strip"):
         _, _, n, lh, lw, cg, cd = _ints(args, 7)
         fl = 2.0 * n * lh * lw * 16 * cg * cd
         by = (n * 4 * lh * lw * cg + n * lh * lw * cd + 16 * cg * cd) * esz
-        if name in ("p2p_igemm_norm_act", "p2p_igemm_norm_small"):          # + the normalised activation written into its concat slice
+        if name == "p2p_igemm_norm_act":          # + the normalised activation written into its concat slice
             by += n * (lh * lw * cd if args[0] == 0 else 4 * lh * lw * cg) * esz
         return {"flops": fl, "mfma": mf, "bytes": by}
     if name in ("p2p_igemm_edge", "p2p_conv_fewin", "p2p_conv_fewout", "p2p_conv_fewin_actbwd"):

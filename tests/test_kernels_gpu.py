@@ -720,81 +720,6 @@ def test_fused_block_conv_instance_norm_activation(op, n, lh, cg, cd, act, cbw, 
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("op,n,lh,cg,cd,sk,act,drop", [
-    (L.OP_G, 3, 4, 256, 512, 2, L.ACT_LEAKY, False),      # down4: 8x8 -> 4x4
-    (L.OP_G, 5, 2, 512, 512, 8, L.ACT_LEAKY, False),      # down5: 4x4 -> 2x2
-    (L.OP_G, 3, 1, 512, 512, 4, L.ACT_LEAKY, False),      # down6: 2x2 -> 1x1 (live taps only)
-    (L.OP_P, 3, 1, 512, 512, 1, L.ACT_RELU, True),        # up1: 1x1 -> 2x2, splitk 1: the convolution writes the raw tensor itself
-    (L.OP_P, 5, 2, 512, 1024, 2, L.ACT_RELU, True),       # up2: 2x2 -> 4x4, 1024 input channels, dropout
-    (L.OP_P, 260, 2, 128, 256, 4, L.ACT_RELU, True),      # several pixel tiles per column tile (1040 lo pixels), ragged last tile
-    (L.OP_G, 70, 4, 128, 128, 16, L.ACT_LEAKY, False)])   # 1120 rows: nine pixel tiles, sixteen K splits each
-def test_small_map_block_in_one_launch_equals_two_launches(dtype, op, n, lh, cg, cd, sk, act, drop):
-    """p2p_igemm_norm_small (round 5): on output maps of <= 16 pixels the convolution's last workgroup per tile sums the K-split
-    slabs and applies InstanceNorm + dropout + activation in the same launch.  Must equal p2p_igemm + p2p_norm_act_fwd BIT FOR BIT
-    (activation slice, raw tensor, statistics) -- same code, same slab order -- leave the tickets zero, and match the oracle.
-    Launched three times over the same buffers: the ticket reset and the device-scope release / acquire between workgroups of
-    different XCDs are what a stale read would break."""
-    assert L.lib().p2p_igemm_norm_small_ok(op, dtype, n, lh, lh, cg, cd, sk) == 1
-    assert L.lib().p2p_igemm_norm_small_ok(L.OP_P, dtype, n, 4, 4, 256, 512, 2) == 0          # 8x8 output map: not a small map
-    assert L.lib().p2p_igemm_norm_small_ok(L.OP_G, dtype, n, 4, 4, 256, 96, 2) == 0           # columns do not fill 128-wide tiles
-    rng = np.random.default_rng(41)
-    hi, lo, w = make_case(rng, n, lh, cg, cd, 2, dtype)
-    g_ref, p_ref, _ = oracle_ops(hi, lo, w, 2)
-    hi_b, lo_b = U.halo_from(hi, dtype), U.halo_from(lo, dtype)
-    wn = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
-    wt = torch.empty(16 * cg * cd, dtype=U.tdt(dtype), device=U.DEV)
-    L.call("p2p_weight_prep", dtype, U.ptr(U.dev(w.reshape(-1))), cg, cd, U.ptr(wn), U.ptr(wt), U.stream())
-    ref, shape = (g_ref, (n, lh, lh, cd)) if op == L.OP_G else (p_ref, (n, 2 * lh, 2 * lh, cg))
-    ncols, res = shape[3], shape[1]
-    gamma = (1 + 0.2 * rng.normal(size=ncols)).astype(np.float32)
-    beta = (0.2 * rng.normal(size=ncols)).astype(np.float32)
-    g_d, b_d = U.dev(gamma), U.dev(beta)
-    mask = torch.as_tensor(rng.integers(0, 2, size=(n * res * res, ncols)).astype(np.uint8)).to(U.DEV) if drop else None
-    wp = U.ptr(wt if op == L.OP_G else wn)
-    slabs = torch.full((sk * n * res * res * ncols + 4,), float("nan"), dtype=torch.float32, device=U.DEV)
-    tickets = torch.zeros(4096, dtype=torch.int32, device=U.DEV)
-
-    def bufs():
-        raw = E.DenseBuf(*shape, U.tdt(dtype), U.DEV)
-        raw.t.fill_(float("nan"))
-        y = E.HaloBuf(n, res, res, ncols + 32, dtype, U.DEV)
-        stats = torch.full((n, ncols, 2), float("nan"), dtype=torch.float32, device=U.DEV)
-        return raw, y, stats
-
-    raw1, y1, st1 = bufs()
-    hv, lv = (hi_b.view(), raw1.view()) if op == L.OP_G else (raw1.view(), lo_b.view())
-    for _ in range(3):
-        L.call("p2p_igemm_norm_small", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), wp, sk, U.ptr(slabs) if sk > 1 else None,
-               U.ptr(g_d), U.ptr(b_d), 1e-3, act, 0.3, U.ptr(mask) if drop else None, C.byref(y1.view(coff=32)), raw1.ptr(), U.ptr(st1),
-               U.ptr(tickets), U.stream())
-    torch.cuda.synchronize()
-    assert int(tickets.abs().sum()) == 0
-    # the two launches
-    raw2, y2, st2 = bufs()
-    hv, lv = (hi_b.view(), raw2.view()) if op == L.OP_G else (raw2.view(), lo_b.view())
-    slabs.fill_(float("nan"))
-    L.call("p2p_igemm", op, dtype, n, lh, lh, cg, cd, C.byref(hv), C.byref(lv), wp, sk, U.ptr(slabs) if sk > 1 else None, None, U.stream())
-    nws = torch.empty(16, dtype=torch.float32, device=U.DEV)
-    L.call("p2p_norm_act_fwd", dtype, n, res, res, ncols, U.ptr(slabs) if sk > 1 else raw2.ptr(), 2 if sk > 1 else 1, sk, n * res * res * ncols,
-           U.ptr(g_d), U.ptr(b_d), 1e-3, act, 0.3, U.ptr(mask) if drop else None, C.byref(y2.view(coff=32)), raw2.ptr() if sk > 1 else None,
-           U.ptr(st2), U.ptr(nws), 64, 1, U.stream())
-    torch.cuda.synchronize()
-    assert torch.equal(raw1.t.view(torch.int16 if dtype == L.BF16 else torch.int32), raw2.t.view(torch.int16 if dtype == L.BF16 else torch.int32))
-    assert torch.equal(st1, st2) and torch.isfinite(st1).all()
-    assert torch.equal(y1.t.view(torch.int16 if dtype == L.BF16 else torch.int32), y2.t.view(torch.int16 if dtype == L.BF16 else torch.int32))
-    # and the oracle: conv -> InstanceNorm(eps 1e-3) -> dropout (x2 where kept) -> activation
-    x = U.dense_to_np(raw1).astype(np.float64)
-    assert U.rel_err(x, ref) < OUT_TOL[dtype]
-    z = rg.instance_norm(torch.tensor(x), torch.tensor(gamma, dtype=F64), torch.tensor(beta, dtype=F64))
-    if drop:
-        z = z * torch.tensor(mask.cpu().numpy().reshape(z.shape).astype(np.float64)) * 2.0
-    want = (torch.relu(z) if act == L.ACT_RELU else rg.leaky_relu(z)).numpy()
-    got = U.halo_to_np(y1)
-    assert U.rel_err(got[..., 32:], want) < OUT_TOL[dtype]
-    assert not got[..., :32].any()           # the other slice of the concat buffer is untouched
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,lh,cg,cd,stride", [(3, 32, 4, 64, 2), (2, 32, 8, 64, 2), (2, 64, 36, 4, 1), (3, 32, 64, 1, 1),
                                                 (2, 16, 1, 64, 2), (20, 64, 33, 8, 1), (3, 32, 32, 128, 2), (2, 16, 64, 128, 2),
                                                 (2, 16, 64, 256, 2), (2, 32, 64, 64, 2), (2, 128, 36, 4, 1), (2, 128, 64, 1, 1)])

@@ -277,38 +277,6 @@ def test_host_side_step_replay_is_bit_identical_to_eager_launching(kind, B):
     assert int(a.mask_counter_dev[0]) == int(b.mask_counter_dev[0])
 
 
-@pytest.mark.parametrize("dtype,B", [(L.BF16, 5), (L.F32, 3), (L.BF16, 64)])
-def test_small_map_blocks_in_one_launch_leave_the_step_bit_identical(dtype, B):
-    """engine.use_norm_tail (round 5): down4-6, up1, up2 run convolution + InstanceNorm + dropout + activation as ONE launch each
-    (p2p_igemm_norm_small).  Three train steps with the device dropout RNG must leave exactly the weights, Adam moments and losses
-    of the two-launch engine -- and five launches per step fewer."""
-    from palette_and_histo_gan_amd import dataset_utils as DU
-    batches = list(DU.synthetic_rgba_ds(3 * B, batch_size=B, palette_size=24, seed=21))
-    runs = []
-    for tail in (True, False):
-        eng = E.Pix2PixEngine(4, 4, "tanh", 64, dtype, seed=9)
-        eng.use_norm_tail = tail
-        eng.replay_enabled = False
-        calls, orig = [], L.call
-        try:
-            def spy(name, *a):
-                calls.append(name)
-                return orig(name, *a)
-            L.call = E.L.call = spy
-            losses = [eng.train_step_rgba(b[0], b[1], 100.0) for b in batches]
-        finally:
-            L.call = E.L.call = orig
-        torch.cuda.synchronize()
-        runs.append((torch.stack(losses).cpu(), eng, calls))
-    (la, a, ca), (lb, b, cb) = runs
-    assert ca.count("p2p_igemm_norm_small") == 5 * len(batches) and cb.count("p2p_igemm_norm_small") == 0
-    assert len(cb) - len(ca) == 5 * len(batches)
-    assert torch.equal(la, lb), (la - lb).abs().max()
-    for sa, sb in ((a.G, b.G), (a.D, b.D)):
-        for buf in ("params", "m", "v"):
-            assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
-
-
 def test_whole_step_hipgraph_replay_equals_eager_launching():
     """engine.graphed_rgba_step captures one train step (every kernel, the forks and joins between the streams through the
     device-only events) and replays it; four steps over changing batches must leave the same weights, moments and losses as four
