@@ -456,6 +456,12 @@ int p2p_event_create(void** ev_out);
 int p2p_event_destroy(void* ev);
 int p2p_event_record(void* ev, void* stream);            /* marks the work issued so far on `stream` */
 int p2p_stream_wait_event(void* stream, void* ev);       /* later work on `stream` waits for the event's latest record */
+/* A record costs the recording stream a packet of its own between two kernels.  p2p_arm_stop_event(ev) instead hands `ev` to the
+ * LAST kernel that the next supporting entry point of this thread launches (p2p_norm_act_bwd, p2p_act_bwd: the calls the weight-
+ * gradient forks follow), as that dispatch's completion signal: equivalent to p2p_event_record(ev, stream) right behind the call.
+ * p2p_disarm_stop_event(&was_pending) afterwards tells whether the event is still unclaimed (record it the ordinary way then). */
+int p2p_arm_stop_event(void* ev);
+int p2p_disarm_stop_event(int* was_pending);
 
 /* ---- step replay (the reference runs train_step as ONE traced tf.function, pix2pix_model.py:62: a step costs the host one
  * call, not one per op; side2side_model.py:73,114 is the loop that issues it) -------------------------------------------------

@@ -89,6 +89,8 @@ SIGNATURES = {
     "p2p_event_destroy": [_vp],
     "p2p_event_record": [_vp, _vp],
     "p2p_stream_wait_event": [_vp, _vp],
+    "p2p_arm_stop_event": [_vp],
+    "p2p_disarm_stop_event": [C.POINTER(C.c_int)],
     "p2p_png_unfilter": [_vp, _i, _i, _i, _vp],
     "p2p_sprites_rgba_batch": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "p2p_gather_rows_i32": [_vp, _i, _i, _vp, _i, _vp, _vp],

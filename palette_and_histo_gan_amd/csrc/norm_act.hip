@@ -799,8 +799,8 @@ extern "C" int p2p_act_bwd(int dtype, int N, int H, int W, int C, const p2p_tens
             long long tv = (long long)N * H * W * (C / vn);
             long long bl = (tv + 255) / 256;
             if (bl > 8192) bl = 8192;
-            P2P_DISPATCH_DTYPE(dtype, (act_bwd_vec_kernel<T><<<dim3((unsigned)bl), 256, 0, (hipStream_t)stream>>>(
-                                          N, H, W, C, make_view(act_out), make_gsrc(g1), make_gsrc(g2), alpha, make_view(draw))));
+            P2P_DISPATCH_DTYPE(dtype, P2P_LAUNCH_LAST((act_bwd_vec_kernel<T>), dim3((unsigned)bl), dim3(256), 0, (hipStream_t)stream,
+                                                      N, H, W, C, make_view(act_out), make_gsrc(g1), make_gsrc(g2), alpha, make_view(draw)));
             return p2p_check_launch("p2p_act_bwd");
         }
     }
@@ -954,8 +954,8 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
         const long long threads = items << lgG;
         const dim3 grid((unsigned)((threads + 255) / 256));
         hipStream_t st = (hipStream_t)stream;
-#define NB_SMALL(P_) norm_act_bwd_small<T, P_><<<grid, 256, 0, st>>>(H * W, W, C, lgG, items, (const T*)raw, stats, gamma, beta, act, alpha, \
-                                                                   mask, make_gsrc(g1), make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)
+#define NB_SMALL(P_) P2P_LAUNCH_LAST((norm_act_bwd_small<T, P_>), grid, dim3(256), 0, st, H * W, W, C, lgG, items, (const T*)raw, stats, gamma, beta, act, \
+                                     alpha, mask, make_gsrc(g1), make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)
         if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(1)); }
         else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(2)); }
         else { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(4)); }
@@ -978,16 +978,16 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
             if (!ws || (long long)N * sp * C * 2 * 4 > ws_bytes) sp = 1;
             dim3 grid(N, C / CG, sp);
             if (sp == 1) {
-                P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T, 0><<<grid, 256, 0, st>>>(
-                                              H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
-                                              make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws)));
+                P2P_DISPATCH_DTYPE(dtype, P2P_LAUNCH_LAST((norm_act_bwd_vec<T, 0>), grid, dim3(256), 0, st,
+                                                          H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
+                                                          make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws));
             } else {
                 P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T, 1><<<grid, 256, 0, st>>>(
                                               H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
                                               make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws)));
-                P2P_DISPATCH_DTYPE(dtype, (norm_act_bwd_vec<T, 2><<<grid, 256, 0, st>>>(
-                                              H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
-                                              make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws)));
+                P2P_DISPATCH_DTYPE(dtype, P2P_LAUNCH_LAST((norm_act_bwd_vec<T, 2>), grid, dim3(256), 0, st,
+                                                          H, W, C, CG, (const T*)raw, stats, gamma, beta, act, alpha, mask, make_gsrc(g1),
+                                                          make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part, ws));
             }
             return p2p_check_launch("p2p_norm_act_bwd");
         }

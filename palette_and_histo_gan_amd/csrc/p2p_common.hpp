@@ -1,6 +1,7 @@
 // Shared device/host helpers for libp2pgan_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/p2pgan.h"
@@ -148,6 +149,18 @@ __device__ __forceinline__ float p2p_valu_zero() {
 __device__ __forceinline__ unsigned p2p_lds32(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
+
+// A fork of a side stream costs the forking stream a marker packet of its own (~4.8 us between two kernels in the step's trace, 17 per
+// step).  An entry point whose LAST launch goes through P2P_LAUNCH_LAST hands an armed event (p2p_arm_stop_event, streams.hip) to that
+// kernel's own dispatch packet as its completion signal (hipExtLaunchKernelGGL stop event): the side stream waits for the event, the
+// forking stream carries no extra packet.  Not armed: a plain launch.
+hipEvent_t p2p_take_stop_event();
+#define P2P_LAUNCH_LAST(kernel, grid, block, shm, st, ...)                                                  \
+    do {                                                                                                    \
+        hipEvent_t stop_ev_ = p2p_take_stop_event();                                                        \
+        if (stop_ev_) hipExtLaunchKernelGGL(kernel, grid, block, shm, st, nullptr, stop_ev_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__);                                 \
+    } while (0)
 
 #define P2P_DISPATCH_DTYPE(dtype, CALL)                         \
     do {                                                        \

@@ -64,7 +64,7 @@ constexpr Entry TABLE[] = {
     P2P_E(p2p_head_dgrad) P2P_E(p2p_head_softmax_cce) P2P_E(p2p_comm_unique_id)
     P2P_E(p2p_comm_init) P2P_E(p2p_comm_allreduce_sum) P2P_E(p2p_comm_destroy)
     P2P_E(p2p_event_create) P2P_E(p2p_event_destroy) P2P_E(p2p_event_record)
-    P2P_E(p2p_stream_wait_event) P2P_E(p2p_png_unfilter) P2P_E(p2p_sprites_rgba_batch)
+    P2P_E(p2p_stream_wait_event) P2P_E(p2p_arm_stop_event) P2P_E(p2p_disarm_stop_event) P2P_E(p2p_png_unfilter) P2P_E(p2p_sprites_rgba_batch)
     P2P_E(p2p_gather_rows_i32) P2P_E(p2p_palette_relabel_batch)
 };
 #undef P2P_E

@@ -39,3 +39,28 @@ extern "C" int p2p_stream_wait_event(void* stream, void* ev) {
     P2P_REQUIRE(e == hipSuccess, "p2p_stream_wait_event: %s", hipGetErrorString(e));
     return 0;
 }
+
+// ---- the completion signal of a kernel as the fork event (P2P_LAUNCH_LAST, p2p_common.hpp) -----------------------------------------
+static thread_local hipEvent_t g_stop_event = nullptr;
+
+hipEvent_t p2p_take_stop_event() {
+    hipEvent_t ev = g_stop_event;
+    g_stop_event = nullptr;
+    return ev;
+}
+
+// The next entry point of this thread whose last launch supports it (p2p_norm_act_bwd, p2p_act_bwd) signals `ev` when that kernel
+// completes -- as p2p_event_record(ev, stream) right behind the call would, without a packet of its own on the stream.
+extern "C" int p2p_arm_stop_event(void* ev) {
+    P2P_REQUIRE(ev, "p2p_arm_stop_event: null event");
+    g_stop_event = (hipEvent_t)ev;
+    return 0;
+}
+
+// Behind that entry point: *was_pending = 1 if no launch took the event (the entry point does not support it, or took a path that
+// does not): the caller records the event the ordinary way.  Leaves nothing armed.
+extern "C" int p2p_disarm_stop_event(int* was_pending) {
+    if (was_pending) *was_pending = g_stop_event != nullptr;
+    g_stop_event = nullptr;
+    return 0;
+}

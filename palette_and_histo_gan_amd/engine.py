@@ -199,10 +199,32 @@ class _SideStream:
     def __init__(self, device, enabled):
         self.enabled = enabled and torch.device(device).type == "cuda"
         self.stream = torch.cuda.Stream(device=device) if self.enabled else None
+        # forks that follow p2p_norm_act_bwd / p2p_act_bwd ride on that kernel's own completion signal (p2p_arm_stop_event) instead of
+        # a marker packet on the main stream; 0 = every fork is an event record
+        self.stop_event_forks = os.environ.get("P2P_STOP_EVENT_FORKS", "1") != "0"
+        self._pending = None
+
+    def prefork(self):
+        """in front of the call whose LAST kernel the next fork() waits for: that kernel's dispatch will signal the fork's event"""
+        # (not under stream capture: a stop event is not a graph node, the captured side branch would start without its dependency)
+        if self.enabled and self.stop_event_forks and not torch.cuda.is_current_stream_capturing():
+            self._pending = _ring_event()
+            _op("p2p_arm_stop_event", self._pending)
 
     def fork(self):
-        if self.enabled:
-            _order(self.stream, torch.cuda.current_stream())
+        if not self.enabled:
+            return
+        ev, self._pending = self._pending, None
+        if ev is not None:
+            unclaimed = C.c_int(0)
+            if L.lib().p2p_disarm_stop_event(C.byref(unclaimed)) != 0:
+                raise L.P2PError(L.lib().p2p_last_error().decode())
+            if not unclaimed.value:         # the kernel carries the event: only the side stream has something to do
+                _op("p2p_stream_wait_event", _raw(self.stream), ev)
+                return
+            if _REC[0] is not None:         # (a replayed step takes the same path: it must leave nothing armed either)
+                _REC[0].append(("p2p_disarm_stop_event", (None,)))
+        _order(self.stream, torch.cuda.current_stream())
 
     def run(self):
         return torch.cuda.stream(self.stream) if self.enabled else _NullCtx()
@@ -1001,13 +1023,17 @@ class Pix2PixEngine:
         return L.GSrc(slabs.data_ptr(), 2, rk[1], buf.n * buf.h * buf.w * buf.c, buf.c, coff)
 
     def _norm_bwd(self, P, name, N, res, c, raw_buf, stats, act, mask, g1, g2, draw_view):
+        """(every caller forks the layer's weight gradient right behind this call: the fork rides on the kernel's completion)"""
         ob, og = P["part_off"][name]
+        self.side.prefork()
         L.call("p2p_norm_act_bwd", self.dtype, N, res, res, c, raw_buf.ptr(), _p(stats), self.G.p(name + ".gamma"),
                self.G.p(name + ".beta"), act, LEAKY_ALPHA, _p(mask) if mask is not None else NULL, C.byref(g1),
                C.byref(g2) if g2 is not None else None, C.byref(draw_view), _p(P["part"], og), _p(P["part"], ob),
                _p(P["nws"]), P["nws"].numel() * 4, self._nsplit(N, res, c, bwd=True), _stream())
 
-    def _act_bwd(self, N, res, c, act_view, g1, g2, draw_view):
+    def _act_bwd(self, N, res, c, act_view, g1, g2, draw_view, fork_follows=False):
+        if fork_follows:
+            self.side.prefork()
         L.call("p2p_act_bwd", self.dtype, N, res, res, c, C.byref(act_view), C.byref(g1),
                C.byref(g2) if g2 is not None else None, LEAKY_ALPHA, C.byref(draw_view), _stream())
 
@@ -1045,7 +1071,7 @@ class Pix2PixEngine:
         # handle value of a NEW stream does not match an old recording).  Adam's hyper-parameters and the dropout seed are NOT
         # part of the key: the records hold the address of their slots (_slot_lr ...), one recording serves every value.
         st = torch.cuda.current_stream()
-        return (kind, B, self.side.enabled, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
+        return (kind, B, self.side.enabled, self.side.stop_event_forks, self.side_hist.enabled, self.fuse_adam, self.use_head_fused, self.hist_fwd3, self.hist_bwd3,
                 self.hist_points, self.fuse_act_bwd, self.split_prep, self.full_pixels, self.use_conv_fewout, self.use_conv_strip, self.use_conv_fewin,
                 self.use_mfma, int(self.splitk_target), int(self.wgemm_want), int(self.wgemm_want_pipe), int(st.cuda_stream), int(st.stream_id),
                 None if dp is None else id(dp)) + extra
@@ -1212,7 +1238,7 @@ class Pix2PixEngine:
         self._wgrad(P, "D", "last", 2 * B, h2, P["d_act"].view(), P["dld"].view(), stride=1, dbias=self.D.g("last.bias"))
         if not self._d_last_dgrad_gated(2 * B, h2, P["dld"].view(), P["d_act"].view(), P["d_draw"].view()):
             self._conv(P, L.OP_P, "D", "last", 2 * B, h2, P["dld"].view(), P["g_dact"].view(), stride=1)
-            self._act_bwd(2 * B, h2, 64, P["d_act"].view(), P["g_dact"].gsrc(), None, P["d_draw"].view())
+            self._act_bwd(2 * B, h2, 64, P["d_act"].view(), P["g_dact"].gsrc(), None, P["d_draw"].view(), fork_follows=True)
         self._wgrad(P, "D", "down", 2 * B, h2, P["dcat"].view(), P["d_draw"].view())
         if P.get("skip_g_through_d"):
             return
@@ -1363,7 +1389,7 @@ class Pix2PixEngine:
                                P["dd"][i].view())
                 hi_view = c[7 - i].view(coff=UP_FILTERS[6 - i])
             else:
-                self._act_bwd(B, res, f, c[5].view(coff=UP_FILTERS[4]), g1, g2, P["dd"][1].view())
+                self._act_bwd(B, res, f, c[5].view(coff=UP_FILTERS[4]), g1, g2, P["dd"][1].view(), fork_follows=True)
                 hi_view = P["src"].view()
             self._wgrad(P, "G", f"down{i}", B, res, hi_view, P["dd"][i].view())
             if i > 1:

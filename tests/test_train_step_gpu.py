@@ -277,6 +277,38 @@ def test_host_side_step_replay_is_bit_identical_to_eager_launching(kind, B):
     assert int(a.mask_counter_dev[0]) == int(b.mask_counter_dev[0])
 
 
+@pytest.mark.parametrize("B,replay", [(4, True), (256, False), (256, True)])
+def test_forks_on_the_kernels_own_completion_signal_order_the_streams_like_event_records(B, replay):
+    """Round 5: the weight-gradient forks behind p2p_norm_act_bwd / p2p_act_bwd ride on that kernel's own completion signal
+    (p2p_arm_stop_event -> hipExtLaunchKernelGGL stop event) instead of an event record between two main-stream kernels.  The side
+    stream must still see the kernel's output: four steps leave exactly the weights and Adam moments of the engine that records
+    every fork (a weight gradient that started early would read a half-written d(raw) tensor), eager and replayed."""
+    from palette_and_histo_gan_amd import dataset_utils as DU
+    batches = list(DU.synthetic_rgba_ds(4 * B, batch_size=B, palette_size=24, seed=17))
+    runs = []
+    for armed in (True, False):
+        eng = E.Pix2PixEngine(4, 4, "tanh", 64, L.BF16, seed=3)
+        eng.side.stop_event_forks = armed
+        eng.replay_enabled = replay
+        armed_calls, orig = [0], E._op
+        try:
+            def spy(name, *a):
+                armed_calls[0] += name == "p2p_arm_stop_event"
+                return orig(name, *a)
+            E._op = spy
+            losses = [eng.train_step_rgba(b[0], b[1], 100.0) for b in batches]
+        finally:
+            E._op = orig
+        torch.cuda.synchronize()
+        assert (armed_calls[0] > 0) == armed
+        runs.append((torch.stack(losses).cpu(), eng))
+    (la, a), (lb, b) = runs
+    assert torch.equal(la, lb), (la - lb).abs().max()
+    for sa, sb in ((a.G, b.G), (a.D, b.D)):
+        for buf in ("params", "m", "v"):
+            assert torch.equal(getattr(sa, buf), getattr(sb, buf)), buf
+
+
 def test_whole_step_hipgraph_replay_equals_eager_launching():
     """engine.graphed_rgba_step captures one train step (every kernel, the forks and joins between the streams through the
     device-only events) and replays it; four steps over changing batches must leave the same weights, moments and losses as four
