@@ -7,9 +7,6 @@ set -e -o pipefail
 TAG=${1:-r02}; CFG=${2:-c2}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-python3 bench.py --config $CFG --steps 50 --warmup 10 --detail $OUT/per_call_$CFG.txt > $OUT/bench_$CFG.log 2>&1
-grep '^{' $OUT/bench_$CFG.log | tail -1 > $OUT/bench_$CFG.json
-echo "bench done"
 rocprofv3 --kernel-trace --stats -d $OUT/kt_$CFG -o kt --output-format csv -- python3 bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-feed-profile > $OUT/kt_$CFG.log 2>&1
 echo "kernel trace done"
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -21,6 +18,12 @@ echo "SQ done"
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $OUT/pmc_lds_$CFG -o pmc --output-format csv -- python3 bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-feed-profile > $OUT/pmc_lds_$CFG.log 2>&1
 echo "LDS done"
 python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE_$CFG $OUT/pmc_WRITE_SIZE_$CFG $OUT/pmc_traffic_${CFG}_bf16.json $CFG > $OUT/pmc_traffic_$CFG.txt
+# the bench line LAST: it quotes roofline.traffic from profiles/pmc_traffic_<config>_bf16.json, which must carry the fingerprint of the
+# sources it runs from -- the counter passes above have just produced it
+cp $OUT/pmc_traffic_${CFG}_bf16.json profiles/pmc_traffic_${CFG}_bf16.json
+python3 bench.py --config $CFG --steps 50 --warmup 10 --detail $OUT/per_call_$CFG.txt > $OUT/bench_$CFG.log 2>&1
+grep '^{' $OUT/bench_$CFG.log | tail -1 > $OUT/bench_$CFG.json
+echo "bench done"
 python3 tools/pmc_sq.py $OUT/pmc_sq_$CFG $OUT/pmc_sq_${CFG}_bf16.json > $OUT/pmc_sq_$CFG.txt
 python3 tools/pmc_sq.py $OUT/pmc_lds_$CFG $OUT/pmc_lds_${CFG}_bf16.json > $OUT/pmc_lds_$CFG.txt
 python3 tools/trace_timeline.py $OUT/kt_$CFG > $OUT/timeline_$CFG.txt 2>&1 || true
