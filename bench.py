@@ -276,7 +276,8 @@ def main():
                                + ("palette-index sprites (1 -> 256-way softmax), " f"lambda_seg={lam_l1}" if indexed else
                                   "RGBA sprites, " f"lambda_l1={lam_l1}") + (f", lambda_hist={lam_hist}, palette {palette}" if lam_hist else ""),
                    "global_batch": B * world, "img_size": S, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if use_graph else ("one p2p_replay call per step" if eng._replays else "eager (Python/ctypes per launch)"),
+                   "launch": "hipGraph replay" if use_graph else (("one p2p_replay call per step" if world == 1 else "replayed: p2p_replay segments with the collectives in between")
+                              if eng._replays else "eager (Python/ctypes per launch)"),
                    "streams": 1 if not eng.side.enabled else (3 if lam_hist else 2),
                    **({"rccl": _collective_info(), "grad_buckets": len(eng.G.buckets)} if world > 1 else {})},
         "losses": [round(float(x), 5) for x in losses.cpu().numpy()],
