@@ -56,11 +56,13 @@ class ScalarLog:
         if len(self._rows) >= self.max_pending:
             self.flush()
 
-    def image(self, name, sheet, step):
-        """tf.summary.image(name, data, step, max_outputs=5) of ONE uint8 RGBA sheet (side2side_model.py:92-93)"""
+    def image(self, name, sheet, step, png_bytes=None):
+        """tf.summary.image(name, data, step, max_outputs=5) of ONE uint8 RGBA sheet (side2side_model.py:92-93); png_bytes: the
+        sheet already encoded (fit() has just written it to `name`)"""
         from . import png
         self.flush()            # keep the file in step order
-        self.events.add_values([tb_events.encode_image_value(name, [png.encode_png(sheet)], sheet.shape[1], sheet.shape[0])], step)
+        data = png_bytes if png_bytes is not None else png.encode_png(sheet)
+        self.events.add_values([tb_events.encode_image_value(name, [data], sheet.shape[1], sheet.shape[0])], step)
 
     def write_raw_pb(self, value, step):
         """tf.summary.experimental.write_raw_pb of one serialized Summary.Value (side2side_model.py:60-61)"""
@@ -223,7 +225,8 @@ class S2SModel(ABC):
                 print(f"Previewing images generated at step {step + 1} (3 test + 3 train)...")
                 sheet = self.preview_generated_images_during_training(examples, save_image_name, step + 1)
                 if self.summary_writer is not None:
-                    self.summary_writer.image(save_image_name, sheet, step=(step + 1) // update_steps)
+                    with open(save_image_name, "rb") as f:          # the file preview_generated_images_during_training has just written
+                        self.summary_writer.image(save_image_name, sheet, step=(step + 1) // update_steps, png_bytes=f.read())
                 if "show_discriminator_output" in callbacks:
                     self.show_discriminated_images("test", 2)          # side2side_model.py:96-97 (numbers instead of plots)
                 if "evaluate_l1" in callbacks:
