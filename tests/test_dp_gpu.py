@@ -123,8 +123,10 @@ def _fit_worker(rank, world, port, q, tmp):
         m.engine.train_step_rgba = spy
         m.fit(5, 2, callbacks=["evaluate_l1"])          # 10 sprites, batch 4: global batches 4, 4, 2 (ragged), 4, 4
         torch.cuda.synchronize()
+        # (round 5) the sharded steps of the repeated batch shape are REPLAYED: recorded C-ABI segments with the collectives in between
+        replayed = [sum(1 for sg in segs if callable(sg)) for segs, _ in m.engine._replays.values()]
         q.put(("fit", rank, world, m.engine.G.params.cpu().numpy().copy(), m.engine.D.params.cpu().numpy().copy(), sizes,
-               m.summary_writer is not None, list(m.checkpoint_manager.saved)))
+               m.summary_writer is not None, list(m.checkpoint_manager.saved), replayed))
         if comm is not None:
             comm.barrier()
             comm.destroy()
@@ -162,9 +164,12 @@ def test_two_rank_fit_equals_one_rank_fit(tmp_path):
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
-    g1, d1, sizes1, log1, ck1 = results[(1, 0)]
-    ga, da, sizes_a, log_a, ck_a = results[(2, 0)]
-    gb, db, sizes_b, log_b, ck_b = results[(2, 1)]
+    g1, d1, sizes1, log1, ck1, rep1 = results[(1, 0)]
+    ga, da, sizes_a, log_a, ck_a, rep_a = results[(2, 0)]
+    gb, db, sizes_b, log_b, ck_b, rep_b = results[(2, 1)]
+    # the steps of the recurring shape were replayed on every rank: one recording, without host-side operations on one GPU, with the
+    # bucket all-reduces, the waits and the tail collective between its segments under data parallelism
+    assert rep1 == [0] and len(rep_a) == len(rep_b) == 1 and rep_a[0] == rep_b[0] >= 3, (rep1, rep_a, rep_b)
     # each rank was handed ITS rows of every global batch, with the global size and its offset
     assert [s[0] for s in sizes1] == [4, 4, 2, 4, 4]
     assert sizes_a == [(2, 4, 0), (2, 4, 0), (1, 2, 0), (2, 4, 0), (2, 4, 0)]
