@@ -1344,6 +1344,66 @@ class Pix2PixEngine:
         self.generator_backward(P)
         return self._finish_step(P, lambda_l1, lambda_hist, apply_update)
 
+    def train_step_rgba_hooked(self, source, real, generator_loss, discriminator_loss, masks=None, apply_update=True):
+        """train_step (pix2pix_model.py:62-89) for a subclass that OVERRIDES the loss hooks (pix2pix_model.py:44-56,242-250 are the
+        reference's own overrides; SURVEY.md B1 lists the hooks as part of the boundary).  The reference differentiates whatever the
+        hooks compute with a GradientTape; here the networks are HIP kernels without a tape, but the hooks only ever see three
+        tensors -- the discriminator's outputs for [real, source] and [fake, source] and the generated image -- so the tape is needed
+        across the hooks alone: the kernels run forward, the hooks are evaluated on torch tensors (autograd gives d(loss)/d(logits)
+        and d(loss)/d(fake)), and those gradients enter the same backward kernels the fused step uses.
+          generator_loss(fake_predicted, fake_image, real_image) -> (total, adversarial, l1[, ...]);  discriminator_loss(real_predicted,
+          fake_predicted) -> (total, real, fake); both written with torch operations on the tensors they are handed (f32, NHWC).
+        Returns [g_total, g_adv, g_l1, g_4th or 0, d_total, d_real, d_fake].  Slower than the fused step by the hooks' own elementwise
+        kernels; single GPU, not replayed (the hooks are host code)."""
+        B = int(source.shape[0])
+        P = self.plan(B)
+        S, ic, h2 = self.S, self.in_ch, self.S // 2
+        assert self.head == "tanh", "the palette-index model has a train_step of its own"
+        self._dp, self._batch_offset = None, 0
+        src_t, real_t = self._to_device(source, ic, B), self._to_device(real, ic, B)
+        self._bind_batch(src_t, real_t)
+        self._pack_source(P, src_t, with_disc=True)
+        self._pack(P, real_t, P["dcat"].view(coff=0), ic)
+        self._early_side(P, masks, apply_update)
+        self.generator_forward(P, masks)
+        real_view, fake_view = P["dcat"].view(coff=0), P["dcat"].view(coff=0, n0=B)
+        fake32 = P.get("fake32_hook")
+        if fake32 is None:
+            fake32 = P["fake32_hook"] = torch.empty(B * S * S * self.out_ch, dtype=torch.float32, device=self.device)
+        # fake = tanh(z): the discriminator's input in the activation dtype, and the unrounded f32 copy the hooks see
+        L.call("p2p_tanh_l1_fwd", self.dtype, B, S, S, self.out_ch, C.byref(P["z"].view()), C.byref(real_view), C.byref(fake_view), 0.0,
+               _p(self.loss_part, 4 * 256), _p(fake32), _stream())
+        self.discriminator_forward(P, 2 * B)
+        logits = P["logits"].t.detach().float().view(2 * B, h2, h2, 1)
+        lg_d = logits.clone().requires_grad_(True)
+        d_loss = discriminator_loss(lg_d[:B], lg_d[B:])
+        d_loss[0].backward()
+        lg_g = logits[B:].clone().requires_grad_(True)
+        fake = fake32.view(B, S, S, self.out_ch).clone().requires_grad_(True)
+        g_loss = generator_loss(lg_g, fake, real_t)
+        g_loss[0].backward()
+        zero = lambda t: torch.zeros_like(t) if t.grad is None else t.grad          # noqa: E731  (a hook may ignore an input)
+        inner = slice(HALO, HALO + h2)
+        P["dld"].t[:, inner, inner, 0] = zero(lg_d).view(2 * B, h2, h2).to(self.tdt)      # pixels [g | 7 padding channels]
+        P["dlg"].t[:, inner, inner, 0] = zero(lg_g).view(B, h2, h2).to(self.tdt)
+        d_fake = zero(fake).contiguous()
+        P["hook_keep"] = (d_fake, lg_d, lg_g, fake)
+        g_extra = L.GSrc(d_fake.data_ptr(), 2, 1, B * S * S * self.out_ch, self.out_ch, 0)
+        P["skip_g_through_d"] = False
+        P["head_dbias_done"] = False
+        self.discriminator_backward(P, B)
+        L.call("p2p_tanh_l1_bwd", self.dtype, B, S, S, self.out_ch, C.byref(fake_view), C.byref(real_view), C.byref(P["g_dcat"].gsrc()),
+               C.byref(g_extra), 0.0, C.byref(P["dz"].view()), _stream())
+        self.generator_backward(P)
+        head = self._adam_head(apply_update)
+        self.side.join()
+        if apply_update:
+            self.apply_adam(g_from=head)
+        self.step_count += 1
+        vals = [g_loss[0], g_loss[1], g_loss[2], g_loss[3] if len(g_loss) > 3 else torch.zeros((), device=self.device),
+                d_loss[0], d_loss[1], d_loss[2]]
+        return torch.stack([v.detach().reshape(()).float() for v in vals])
+
     def generator_backward(self, P):
         """Backward of UnetGenerator from dz (the gradient at the head's pre-activation)."""
         B, S = P["B"], self.S

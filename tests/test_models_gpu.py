@@ -85,13 +85,14 @@ def test_scalar_log_does_not_synchronise_and_hooks_fail_loudly(tmp_path, monkeyp
     model.summary_writer.flush()
     assert not model.summary_writer._rows
 
-    class Custom(M.Pix2PixModel):          # a subclass that changes the loss cannot be honoured by the fused step
+    class Custom(M.Pix2PixIndexedModel):      # the palette-index step is fused around its softmax head: ITS hooks cannot be replaced
         def generator_loss(self, fake_predicted, fake_image, real_image):
             return super().generator_loss(fake_predicted, fake_image, real_image)
 
-    c = Custom(train, train, "front2right", "pix2pix-hooks-test", lambda_l1=100.0)
+    ids = D.synthetic_indexed_ds(4, batch_size=4)
+    c = Custom(ids, ids, "front2right", "pix2pix-hooks-test")
     with pytest.raises(NotImplementedError, match="fused"):
-        c.train_step(next(iter(train)), 0, 1)
+        c.train_step(next(iter(ids)), 0, 1)
 
     class OneChannel(M.Pix2PixIndexedModel):        # the builders take the reference's arguments (networks.py:39,53)
         def create_generator(self):
@@ -150,6 +151,114 @@ def test_histogram_and_indexed_models_train(tmp_path, monkeypatch):
     assert idx.dtype == torch.int32 and tuple(idx.shape) == (4, 64, 64, 1) and tuple(probs.shape) == (4, 64, 64, 256)
     assert torch.equal(idx[..., 0].long(), torch.argmax(probs, -1))          # palette-index argmax, bit-exact
     np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
+def _params(seed):
+    rng = np.random.default_rng(seed)
+    Gp = rg.perturb_affine(rg.init_params(rg.generator_param_shapes(4, 4), rng, F64), rng)
+    Dp = rg.perturb_affine(rg.init_params(rg.discriminator_param_shapes(4), rng, F64), rng)
+    return rng, Gp, Dp
+
+
+def test_overridden_loss_hooks_run_through_autograd_across_the_hooks():
+    """SURVEY.md B1 / VERDICT r04 missing-3: generator_loss / discriminator_loss are hooks subclasses rely on (the reference's own
+    Pix2PixHistogramModel overrides one, pix2pix_model.py:242-250).  A subclass that overrides them gets engine.train_step_rgba_hooked:
+    kernels forward, the hooks on torch tensors with autograd, their gradients into the backward kernels.
+    (a) hooks that restate the reference's formulas must reproduce the FUSED step: losses 1e-6, every gradient tensor 1e-5 of its
+        max-norm (f32 mode, injected dropout masks);
+    (b) hooks of a different loss family (least-squares GAN + a weighted L2 image term) against the float64 oracle graph
+        differentiated by torch autograd: losses 1e-5, gradients 1e-4 of max-norm."""
+    B, S = 2, 64
+    rng, Gp, Dp = _params(71)
+    src, tgt = rg.synthetic_rgba_batch(rng, B, S, palette_size=24)
+    masks = [rng.integers(0, 2, size=s).astype(np.uint8) for s in rg.dropout_mask_shapes(B, S)]
+    to_np = lambda p: {k: v.numpy() for k, v in p.items()}      # noqa: E731
+
+    def engine():
+        eng = E.Pix2PixEngine(4, 4, "tanh", S, L.F32)
+        eng.set_params(to_np(Gp), to_np(Dp))
+        return eng
+
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def gen_ref(fp, fake, real):
+        adv = bce(fp, torch.ones_like(fp))
+        l1 = (real - fake).abs().mean()
+        return adv + 100.0 * l1, adv, l1
+
+    def disc_ref(rp, fp):
+        r, f = bce(rp, torch.ones_like(rp)), bce(fp, torch.zeros_like(fp))
+        return r + f, r, f
+
+    fused, hooked = engine(), engine()
+    out_f = fused.train_step_rgba(src, tgt, 100.0, masks=masks, apply_update=False).cpu().numpy()
+    out_h = hooked.train_step_rgba_hooked(src, tgt, gen_ref, disc_ref, masks=masks, apply_update=False).cpu().numpy()
+    for i in (0, 1, 2, 4, 5, 6):
+        assert abs(out_h[i] - out_f[i]) <= 1e-6 * abs(out_f[i]), (i, out_h[i], out_f[i])
+    for a, b in ((hooked.G, fused.G), (hooked.D, fused.D)):
+        ga, gb = a.export(a.grads), b.export(b.grads)
+        for k in ga:
+            assert np.abs(ga[k] - gb[k]).max() <= 1e-5 * np.abs(gb[k]).max() + 1e-12, k
+
+    # (b) least-squares GAN hooks against the oracle graph under autograd
+    def gen_ls(fp, fake, real):
+        adv = ((fp - 1.0) ** 2).mean()
+        l2 = ((real - fake) ** 2).mean()
+        return adv + 25.0 * l2, adv, l2
+
+    def disc_ls(rp, fp):
+        r, f = ((rp - 1.0) ** 2).mean(), (fp ** 2).mean()
+        return 0.5 * (r + f), r, f
+
+    eng = engine()
+    out = eng.train_step_rgba_hooked(src, tgt, gen_ls, disc_ls, masks=masks, apply_update=False).cpu().numpy()
+    Gl = {k: v.clone().requires_grad_(True) for k, v in Gp.items()}
+    Dl = {k: v.clone().requires_grad_(True) for k, v in Dp.items()}
+    s64, t64 = torch.tensor(src, dtype=F64), torch.tensor(tgt, dtype=F64)
+    fake = rg.unet_generator(Gl, s64, [torch.tensor(m, dtype=F64) for m in masks], "tanh")
+    rp, fp = rg.patch_discriminator(Dl, t64, s64), rg.patch_discriminator(Dl, fake, s64)
+    g = gen_ls(fp, fake, t64)
+    d = disc_ls(rp, fp)
+    g_grads = torch.autograd.grad(g[0], list(Gl.values()), retain_graph=True, allow_unused=True)
+    d_grads = torch.autograd.grad(d[0], list(Dl.values()), allow_unused=True)
+    want = [float(g[0].detach()), float(g[1].detach()), float(g[2].detach()), 0.0, float(d[0].detach()), float(d[1].detach()), float(d[2].detach())]
+    for i in (0, 1, 2, 4, 5, 6):
+        assert abs(out[i] - want[i]) <= 1e-5 * abs(want[i]), (i, out[i], want[i])
+    for store, names, grads in ((eng.G, list(Gl), g_grads), (eng.D, list(Dl), d_grads)):
+        got = store.export(store.grads)
+        for k, gr in zip(names, grads):
+            ref = np.zeros_like(got[k]) if gr is None else gr.numpy()
+            assert np.abs(got[k] - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-12, (k, np.abs(got[k] - ref).max(), np.abs(ref).max())
+
+
+def test_a_subclass_with_its_own_losses_trains_through_fit(tmp_path, monkeypatch):
+    """the class-level route: a subclass of Pix2PixModel with least-squares losses goes through fit() (bf16, device dropout RNG), its
+    hooks are called every step with differentiable tensors, the loss goes down and the reference's scalars are logged"""
+    monkeypatch.chdir(tmp_path)
+    calls = []
+
+    class LsGan(M.Pix2PixModel):
+        def generator_loss(self, fake_predicted, fake_image, real_image):
+            calls.append((fake_predicted.requires_grad, fake_image.requires_grad, tuple(fake_image.shape)))
+            adv = ((fake_predicted - 1.0) ** 2).mean()
+            l1 = (real_image - fake_image).abs().mean()
+            return adv + self.lambda_l1 * l1, adv, l1
+
+        def discriminator_loss(self, real_predicted, fake_predicted):
+            r, f = ((real_predicted - 1.0) ** 2).mean(), (fake_predicted ** 2).mean()
+            return 0.5 * (r + f), r, f
+
+    train = D.synthetic_rgba_ds(8, batch_size=4, palette_size=24)
+    m = LsGan(train, train, "front2right", "pix2pix-lsgan-test", lambda_l1=100.0)
+    w0 = m.generator.trainable_variables[0].clone()
+    first = [float(x) for x in m.train_step(next(iter(train)), 0, 1)[0]]
+    m.fit(30, 10)
+    last = [float(x) for x in m.train_step(next(iter(train)), 31, 10)[0]]
+    assert len(calls) == 32 and all(c == (True, True, (4, 64, 64, 4)) for c in calls)
+    assert not torch.equal(w0, m.generator.trainable_variables[0]) and m.engine.G.t == 32
+    assert last[2] < 0.6 * first[2], (first, last)          # the L1 term fell
+    rows = [r for r in open(m.summary_writer.path)]
+    assert any("generator/l1_loss" in r for r in rows) and any("discriminator/total_loss" in r for r in rows)
 
 
 def test_engine_reproduces_golden_vectors():
