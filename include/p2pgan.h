@@ -281,6 +281,12 @@ int p2p_tanh_l1_bwd_pad8(int dtype, int N, int H, int W, const p2p_tensor* fake,
  * hist[n][c][i][j] = sum_p Iy[p] k(u_p - d_i) k(v_p - d_j) for component c (the reference's (B,64,64,3) tensor
  * transposed and before its division by the per-image total, histogram.py:75-79). */
 int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tensor* img, float* hist, void* stream);
+/* The same with the reference function's other arguments (histogram.py:36): hist[N][3][size][size], size 2..128, bin centres
+ * linspace(-3, 3, size), method 0 = "inverse-quadratic", 1 = "RBF", 2 = any other string (the reference then applies no kernel
+ * function: histogram.py:20-27 has no third branch), sigma > 0.  General f32 kernel for evaluation code; no reference call site
+ * leaves the defaults, which the specialised kernels serve. */
+int p2p_rgbuv_hist_general(int dtype, int N, int H, int W, const p2p_tensor* img, int size, int method, float sigma, float* hist,
+                           void* stream);
 
 /* The same raw histograms [N][3][64][64], all three colour components of an image from THREE shared kernel rows per pixel
  * (the components' (u, v) are (a, b), (-a, c), (-b, -c) of three log-chroma differences and the bin grid is symmetric,

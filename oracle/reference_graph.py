@@ -250,8 +250,9 @@ def discriminator_loss(real_pred, fake_pred):
     return fake + real, real, fake
 
 
-def rgbuv_histogram(image, size=64, sigma=0.02):
-    """calculate_rgbuv_histogram, method='inverse-quadratic' (histogram.py:35-81)."""
+def rgbuv_histogram(image, size=64, sigma=0.02, method="inverse-quadratic"):
+    """calculate_rgbuv_histogram (histogram.py:35-81); method "RBF", "inverse-quadratic", or anything else: the reference applies no
+    kernel function then (histogram.py:20-27 has two branches)."""
     eps = 1e-6
     sigma_sqr = sigma ** 2
     dom = torch.linspace(-3.0, 3.0, size, dtype=image.dtype)              # histogram.py:55
@@ -262,8 +263,11 @@ def rgbuv_histogram(image, size=64, sigma=0.02):
     def component(comp, p1, p2):                                           # histogram.py:4-32
         Iu = (torch.log(comp + eps) - torch.log(p1 + eps)).unsqueeze(-1)
         Iv = (torch.log(comp + eps) - torch.log(p2 + eps)).unsqueeze(-1)
-        du = 1.0 / (1.0 + (Iu - dom) ** 2 / sigma_sqr)
-        dv = 1.0 / (1.0 + (Iv - dom) ** 2 / sigma_sqr)
+        du, dv = (Iu - dom) ** 2 / sigma_sqr, (Iv - dom) ** 2 / sigma_sqr        # :20-21
+        if method == "RBF":                                                       # :22-24
+            du, dv = torch.exp(-du), torch.exp(-dv)
+        elif method == "inverse-quadratic":                                       # :25-27
+            du, dv = 1.0 / (1.0 + du), 1.0 / (1.0 + dv)
         a = (Iy * du).transpose(1, 2)
         return a @ dv
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     "p2p_dropout_mask": [_vp, _ll, _ll, _ll, _vp],
     "p2p_rgbuv_hist_fwd": [_i, _i, _i, _i, _TP, _vp, _vp],
     "p2p_hist_normalize": [_vp, _i, _vp, _vp],
+    "p2p_rgbuv_hist_general": [_i, _i, _i, _i, _TP, _i, _i, _f, _vp, _vp],
     "p2p_rgbuv_hist_fwd3": [_i, _i, _i, _i, _TP, _vp, _vp, _i, _vp, _vp, _vp],
     "p2p_rgbuv_points": [_i, _i, _i, _i, _TP, _i, _vp, _vp, _vp],
     "p2p_hellinger_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],

@@ -856,6 +856,80 @@ extern "C" int p2p_hist_normalize(const float* raw, int N, float* out, void* str
     return p2p_check_launch("p2p_hist_normalize");
 }
 
+// ---- forward with the reference's other arguments (histogram.py:36: size, method, sigma) --------------------------------------------
+// No call site of the reference uses anything but (64, "inverse-quadratic", 0.02) -- the specialised kernels above and below serve
+// that -- but the function's signature takes them, so the standalone call does too: one workgroup per (image, component), kernel
+// rows of a batch of pixels in LDS, every thread owns size^2 / 256 bins and adds the pixels in pixel order (deterministic).  f32
+// throughout, no matrix pipe: a few milliseconds per batch, for evaluation code.
+// method: 0 = inverse-quadratic 1 / (1 + t^2 / sigma^2), 1 = RBF exp(-t^2 / sigma^2), 2 = anything else: the reference applies NO
+// kernel function then and multiplies the scaled squared distances themselves (histogram.py:20-27 has no third branch).
+template <typename T>
+__global__ __launch_bounds__(256) void rgbuv_hist_general_kernel(int H, int W, TView img, int S, int method, float inv_sigma2,
+                                                                 float* __restrict__ hist) {
+    constexpr int PB = 32, MAXB = 64;               // pixels per batch; bins per thread (S <= 128)
+    extern __shared__ float gsm[];                  // ku[PB][S] | kv[PB][S] | iy[PB]
+    float* const ku = gsm;
+    float* const kv = gsm + PB * S;
+    float* const iyL = gsm + 2 * PB * S;
+    const int n = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const int HW = H * W, nb = (S * S + 255) / 256;
+    int ca, cp1, cp2;
+    comp_order(c, ca, cp1, cp2);
+    float acc[MAXB];
+    int ij[MAXB];                                    // (i << 8) | j of the thread's k-th bin: registers (the loops below are unrolled)
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k) {
+        acc[k] = 0.f;
+        const int bin = min(tid + 256 * k, S * S - 1);
+        ij[k] = ((bin / S) << 8) | (bin % S);
+    }
+    const float step = 6.0f / (float)(S - 1);
+    for (int p0 = 0; p0 < HW; p0 += PB) {
+        const int np = min(PB, HW - p0);
+        for (int idx = tid; idx < np * S; idx += 256) {
+            const int p = idx / S, i = idx - p * S;
+            float x[3];
+            load_rgb01<T>(img, n, p0 + p, W, x);
+            const float la = logf(x[ca] + HIST_EPS);
+            const float u = la - logf(x[cp1] + HIST_EPS), v = la - logf(x[cp2] + HIST_EPS);
+            const float d = -3.0f + (float)i * step;
+            float tu = (u - d) * (u - d) * inv_sigma2, tv = (v - d) * (v - d) * inv_sigma2;
+            if (method == 0) { tu = 1.0f / (1.0f + tu); tv = 1.0f / (1.0f + tv); }
+            else if (method == 1) { tu = expf(-tu); tv = expf(-tv); }
+            ku[idx] = tu;
+            kv[idx] = tv;
+            if (i == 0) iyL[p] = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + HIST_EPS);
+        }
+        __syncthreads();
+        for (int p = 0; p < np; ++p) {
+            const float iy = iyL[p];
+            const float* const kup = ku + p * S;
+            const float* const kvp = kv + p * S;
+#pragma unroll
+            for (int k = 0; k < MAXB; ++k)
+                if (k < nb) acc[k] += iy * kup[ij[k] >> 8] * kvp[ij[k] & 255];
+        }
+        __syncthreads();
+    }
+    float* out = hist + ((long long)n * 3 + c) * S * S;
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k) {
+        const int bin = tid + 256 * k;
+        if (k < nb && bin < S * S) out[bin] = acc[k];
+    }
+}
+
+extern "C" int p2p_rgbuv_hist_general(int dtype, int N, int H, int W, const p2p_tensor* img, int size, int method, float sigma,
+                                      float* hist, void* stream) {
+    P2P_REQUIRE(N > 0 && H > 0 && W > 0 && img && img->ptr && hist, "p2p_rgbuv_hist_general: bad args");
+    P2P_REQUIRE(size >= 2 && size <= 128 && sigma > 0.f && method >= 0 && method <= 2, "p2p_rgbuv_hist_general: size in 2..128, sigma > 0, method 0..2");
+    const size_t shm = (size_t)(2 * 32 * size + 32) * sizeof(float);
+    const float inv_sigma2 = 1.0f / (sigma * sigma);
+    P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_general_kernel<T><<<dim3(N, 3), 256, shm, (hipStream_t)stream>>>(H, W, make_view(img), size, method,
+                                                                                                           inv_sigma2, hist)));
+    return p2p_check_launch("p2p_rgbuv_hist_general");
+}
+
 extern "C" int p2p_rgbuv_hist_fwd(int dtype, int N, int H, int W, const p2p_tensor* img, float* hist, void* stream) {
     P2P_REQUIRE(N > 0 && H > 0 && W > 0 && img && img->ptr && hist, "p2p_rgbuv_hist_fwd: bad args");
     P2P_DISPATCH_DTYPE(dtype, (rgbuv_hist_fwd_kernel<T><<<dim3(N, 3), 256, 0, (hipStream_t)stream>>>(H, W, make_view(img), hist)));

@@ -58,7 +58,7 @@ constexpr Entry TABLE[] = {
     P2P_E(p2p_adam_prep_batched) P2P_E(p2p_pack_input) P2P_E(p2p_pack_pair)
     P2P_E(p2p_pack_pair_idx) P2P_E(p2p_pack_input_multi) P2P_E(p2p_finish_losses)
     P2P_E(p2p_unpack) P2P_E(p2p_dropout_mask) P2P_E(p2p_rgbuv_hist_fwd)
-    P2P_E(p2p_hist_normalize) P2P_E(p2p_rgbuv_hist_fwd3) P2P_E(p2p_rgbuv_points)
+    P2P_E(p2p_hist_normalize) P2P_E(p2p_rgbuv_hist_general) P2P_E(p2p_rgbuv_hist_fwd3) P2P_E(p2p_rgbuv_points)
     P2P_E(p2p_hellinger_fwd) P2P_E(p2p_hellinger_finish) P2P_E(p2p_rgbuv_hist_hellinger_bwd)
     P2P_E(p2p_rgbuv_hist_hellinger_bwd3) P2P_E(p2p_softmax_cce_argmax) P2P_E(p2p_argmax_lastdim)
     P2P_E(p2p_head_dgrad) P2P_E(p2p_head_softmax_cce) P2P_E(p2p_comm_unique_id)

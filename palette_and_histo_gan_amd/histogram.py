@@ -13,24 +13,33 @@ from . import _lib as L
 
 
 def calculate_rgbuv_histogram(image_batch, size=64, method="inverse-quadratic", sigma=0.02, device="cuda:0"):
-    """histogram.py:35-81 (size 64, inverse-quadratic kernel, sigma 0.02 are the only values the reference uses).
-    (B, S, S, 4) values in [-1, 1] -> normalised (B, 64, 64, 3) f32 device tensor.  Two launches through the C ABI
-    (p2p_rgbuv_hist_fwd + p2p_hist_normalize) on the current stream; no engine, no parameters are created for it."""
-    if size != 64 or method != "inverse-quadratic" or abs(sigma - 0.02) > 1e-12:
-        raise NotImplementedError("only the reference's call (size=64, inverse-quadratic, sigma=0.02) is built")
+    """histogram.py:35-81.  (B, S, S, 4) values in [-1, 1] -> normalised (B, size, size, 3) f32 device tensor.  The reference's only
+    call (size 64, inverse-quadratic kernel, sigma 0.02) runs the specialised kernels (p2p_rgbuv_hist_fwd + p2p_hist_normalize); any
+    other size (2..128), sigma or method goes through the general kernel p2p_rgbuv_hist_general -- method "RBF", "inverse-quadratic",
+    or anything else, for which the reference applies NO kernel function (histogram.py:20-27 has no third branch; "thresholding" is
+    documented there but not implemented) and so does this.  Launches on the current stream; no engine, no parameters are created."""
     L.lib()          # fail loudly if the HIP library is missing: there is no CPU path
     dev = torch.device(device)
     img = torch.as_tensor(image_batch).to(device=dev, dtype=torch.float32).contiguous()
-    if img.dim() != 4 or img.shape[3] != 4:
-        raise ValueError(f"expected a (B, H, W, 4) batch, got {tuple(img.shape)}")
-    B, H, W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+    if img.dim() != 4 or img.shape[3] < 3:
+        raise ValueError(f"expected a (B, H, W, >= 3) batch, got {tuple(img.shape)}")
+    B, H, W, ch = (int(x) for x in img.shape)
+    size, sigma = int(size), float(sigma)
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        raw = torch.empty(B * 3 * 64 * 64, dtype=torch.float32, device=dev)
-        out = torch.empty((B, 64, 64, 3), dtype=torch.float32, device=dev)
-        L.call("p2p_rgbuv_hist_fwd", L.F32, B, H, W, C.byref(L.Tensor(img.data_ptr(), H * W, W, 4)), C.c_void_p(raw.data_ptr()), stream)
-        L.call("p2p_hist_normalize", C.c_void_p(raw.data_ptr()), B, C.c_void_p(out.data_ptr()), stream)
-    return out
+        view = L.Tensor(img.data_ptr(), H * W, W, ch)
+        raw = torch.empty(B * 3 * size * size, dtype=torch.float32, device=dev)
+        if size == 64 and method == "inverse-quadratic" and abs(sigma - 0.02) <= 1e-12:
+            out = torch.empty((B, 64, 64, 3), dtype=torch.float32, device=dev)
+            L.call("p2p_rgbuv_hist_fwd", L.F32, B, H, W, C.byref(view), C.c_void_p(raw.data_ptr()), stream)
+            L.call("p2p_hist_normalize", C.c_void_p(raw.data_ptr()), B, C.c_void_p(out.data_ptr()), stream)
+            return out
+        if not 2 <= size <= 128 or sigma <= 0:
+            raise ValueError("size must be in 2..128 and sigma positive")
+        code = {"inverse-quadratic": 0, "RBF": 1}.get(method, 2)
+        L.call("p2p_rgbuv_hist_general", L.F32, B, H, W, C.byref(view), size, code, sigma, C.c_void_p(raw.data_ptr()), stream)
+        h = raw.view(B, 3, size, size).permute(0, 2, 3, 1)            # the reference stacks the components last (histogram.py:75)
+        return (h / h.sum(dim=(1, 2, 3), keepdim=True)).contiguous()    # :78-79
 
 
 def hellinger_loss(y_true, y_pred):

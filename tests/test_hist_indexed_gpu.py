@@ -46,8 +46,20 @@ def test_rgbuv_histogram_forward_matches_oracle():
     assert not made and torch.equal(hf, eng.rgbuv_histogram(fake))
     want = rg.hellinger_loss(rg.rgbuv_histogram(torch.tensor(tgt, dtype=F64)), rg.rgbuv_histogram(torch.tensor(fake, dtype=F64)))
     assert abs(float(H.hellinger_loss(ht, hf)) - float(want)) <= 1e-4 * float(want)
-    with pytest.raises(NotImplementedError):
-        H.calculate_rgbuv_histogram(tgt, method="RBF")
+    # the function's other arguments (histogram.py:36; VERDICT r04 missing-4): sizes, sigma, the RBF kernel and the reference's
+    # fall-through for any other method string (no kernel function applied) through the general kernel, against the f64 oracle
+    for size, method, sigma in ((64, "RBF", 0.02), (32, "inverse-quadratic", 0.05), (48, "RBF", 0.1), (16, "thresholding", 0.02),
+                                (128, "inverse-quadratic", 0.02), (64, "inverse-quadratic", 0.03)):
+        got = H.calculate_rgbuv_histogram(fake, size=size, method=method, sigma=sigma).cpu().numpy()
+        ref = rg.rgbuv_histogram(torch.tensor(fake, dtype=F64), size=size, sigma=sigma, method=method).numpy()
+        assert got.shape == (3, size, size, 3)
+        np.testing.assert_allclose(got.sum(axis=(1, 2, 3)), 1.0, rtol=1e-5)
+        assert U.rel_err(got, ref) < 1e-4, (size, method, sigma, U.rel_err(got, ref))
+    # the default arguments through BOTH kernels give the same histogram
+    gen = H.calculate_rgbuv_histogram(fake, size=64, method="inverse-quadratic", sigma=0.02 + 1e-9).cpu().numpy()
+    assert U.rel_err(gen, hf.cpu().numpy()) < 1e-5
+    with pytest.raises(ValueError):
+        H.calculate_rgbuv_histogram(tgt, size=256)
 
 
 def test_histogram_tail_batches_small_image():
