@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--no-replay", action="store_true", help="issue every launch from Python (P2P_REPLAY=0) instead of one p2p_replay call per step")
     ap.add_argument("--one-stream", action="store_true", help="no weight-gradient / histogram side streams")
     ap.add_argument("--host-batches", action="store_true", help="hand train_step HOST (numpy) batches: every step uploads its batch over PCIe "
-                    "inside the timed region.  NOT the headline (the product's datasets keep the sprite set in HBM and produce device batches); "
+                    "inside the timed region, on a copy stream (dataset_utils.upload_async).  NOT the headline (the product's datasets keep the sprite set in HBM and produce device batches); "
                     "DESIGN.md section 6 quotes this rate beside it")
     ap.add_argument("--no-mfma", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one captured hipGraph (N=1 only). Measured "
@@ -242,6 +242,11 @@ def main():
         eng.side.enabled = eng.side_hist.enabled = False
 
     def run_step_eager():
+        if args.host_batches:       # as the model classes do for host batches: upload beside the previous step's kernels
+            s_d, t_d = DU.upload_async([src_d, tgt_d], device)
+            if indexed:
+                return eng.train_step_indexed(s_d, t_d, lam_l1, global_batch=B * world, dp=comm, batch_offset=rank * B)
+            return eng.train_step_rgba(s_d, t_d, lam_l1, lam_hist, global_batch=B * world, dp=comm, batch_offset=rank * B)
         if indexed:
             return eng.train_step_indexed(src_d, tgt_d, lam_l1, global_batch=B * world, dp=comm, batch_offset=rank * B)
         return eng.train_step_rgba(src_d, tgt_d, lam_l1, lam_hist, global_batch=B * world, dp=comm, batch_offset=rank * B)

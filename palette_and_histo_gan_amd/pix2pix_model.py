@@ -192,9 +192,16 @@ class Pix2PixModel(S2SModel):
             return tensors, batch.global_batch, batch.offset, dp
         Bg = len(tensors[0])
         if dp is None:
-            return tensors, Bg, 0, None
+            return self._upload(tensors), Bg, 0, None
         lo, hi = shard_bounds(Bg, dp.world, dp.rank)
-        return [t[lo:hi] for t in tensors], Bg, lo, dp
+        return self._upload([t[lo:hi] for t in tensors]), Bg, lo, dp
+
+    def _upload(self, tensors):
+        """host batches (numpy / CPU tensors) go up on a copy stream, beside the previous step's kernels (dataset_utils.upload_async)"""
+        if len(tensors[0]) == 0 or self.engine.device.type != "cuda":
+            return tensors
+        from .dataset_utils import upload_async
+        return upload_async(tensors, self.engine.device)
 
     def train_step(self, batch, step, update_steps):
         """pix2pix_model.py:62-89"""

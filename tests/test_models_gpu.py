@@ -153,6 +153,27 @@ def test_histogram_and_indexed_models_train(tmp_path, monkeypatch):
     np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
 
 
+def test_host_batches_upload_on_a_copy_stream_and_train_identically(tmp_path, monkeypatch):
+    """A batch source that yields numpy arrays (a tf.data pipeline of the reference through Dataset.from_batches) is uploaded by
+    dataset_utils.upload_async on a stream of its own, beside the previous step's kernels; six steps (the replayed ones included) must
+    leave exactly the weights of the model that is fed device tensors."""
+    monkeypatch.chdir(tmp_path)
+    batches = list(D.synthetic_rgba_ds(24, batch_size=4, palette_size=24, seed=31))
+    assert isinstance(batches[0][0], np.ndarray)
+    runs = []
+    for host in (True, False):
+        m = M.Pix2PixModel(None, None, "front2right", "upload-test", lambda_l1=100.0, seed=7)
+        for t, b in enumerate(batches):
+            bb = b if host else tuple(torch.as_tensor(x).cuda() for x in b)
+            g_loss, d_loss = m.train_step(bb, t, 1)
+        torch.cuda.synchronize()
+        runs.append((m, [float(x) for x in g_loss + d_loss]))
+    (a, la), (b, lb) = runs
+    assert la == lb
+    assert torch.equal(a.engine.G.params, b.engine.G.params) and torch.equal(a.engine.D.params, b.engine.D.params)
+    assert len(a.engine._replays) == 1 and len(D._COPY_STREAMS) == 1
+
+
 def _params(seed):
     rng = np.random.default_rng(seed)
     Gp = rg.perturb_affine(rg.init_params(rg.generator_param_shapes(4, 4), rng, F64), rng)
