@@ -213,7 +213,13 @@ int p2p_norm_act_fwd_tail(int dtype, int N, int H, int W, int C,
 
 /* Backward of the fused block: dact = g1 + g2 (pointwise gradient sources), through dropout/activation
  * (sign recomputed from raw+stats) and the InstanceNorm closed form.  Writes d(raw)
- * into the haloed view `draw` and per-image partials dgamma_part/dbeta_part [N][C] (f32).  ws/nsplit as above. */
+ * into the haloed view `draw` and per-image partials dgamma_part/dbeta_part [N][C] (f32).  ws/nsplit as above;
+ * maps of up to 64x64 pixels whose (image, channel group) slice fits a workgroup's registers take one launch that
+ * reads every operand once, whatever nsplit says (the same holds for p2p_norm_act_fwd without conv-epilogue statistics).
+ * nsplit | 0x100 (nsplit > 0, forward and backward): the two-pass forms only, whose order of the per-channel sums does
+ * not depend on N -- an image's result then does not depend on the batch it sits in (the engine's f32 parity mode);
+ * nsplit | 0x200: the one-launch forms with the geometry they would pick for N = 256 (wide channel groups, several
+ * pixels per thread), so that tests reach those variants with a small batch. */
 int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C,
                      const void* raw, const float* stats, const float* gamma, const float* beta,
                      int act, float alpha, const unsigned char* mask,

@@ -545,9 +545,10 @@ static BrigPlan brig_plan(int op, int dtype, int N, int LH, int LW, int Cg, int 
     {
         const char* e = getenv("P2P_BRIG_MIN_WG");
         const long long min_wg = e ? atoi(e) : 160;
-        // (launch-bound batches keep the fused block: at batch 4 the step is a chain of ~100 dependent launches and the extra
-        // normalisation launch of the im2col route costs more than the idle chip -- c1 0.935 vs 1.026 ms)
-        if (N >= 32 && (long long)p.ntiles * p.nnt < min_wg) return p;
+        // (r04 kept the fused block below batch 32: the step was issued from Python then and the extra normalisation launch cost
+        // host time, c1 0.935 vs 1.026 ms.  With the step replayed by the library and the one-pass normalisation kernels of
+        // norm_act.hip the im2col route wins at every small batch: c1 0.848 -> 0.775 ms, profiles/r05_exp_small_batch.txt)
+        if ((long long)p.ntiles * p.nnt < min_wg) return p;
     }
     if (mode == 1) {
         p.BR = p.rpt + 2;

@@ -546,6 +546,201 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Register-resident form (r05): one launch, every operand read ONCE.  A workgroup owns (image, CG channels) like MODE 0 above,
+// but a thread keeps its <= PPL pixels (x packed in the storage type, d(yhat) in f32) in registers between the reduction and
+// the apply pass instead of reading them again, and all of its loads are issued before the first use.  Geometry (host side,
+// norm_bwd_reg_geom): the widest channel group whose pixel rows fit PPL <= 8 and that still yields
+// >= 512 workgroups, else the narrowest one -- at batch 4 a 16x16x128 tensor becomes 64 workgroups of one pixel per thread
+// instead of 16 workgroups looping twice over 16 pixels (c1: 29 us for two launches -> one launch-sized kernel).  The channel
+// groups of one image sit on ONE XCD, next to each other in dispatch order (workgroup id = ((n / 8) * groups + group) * 8 + n % 8):
+// with groups narrower than a 128-byte line the line's other readers find it in that XCD's L2.
+template <typename T, int PPL>
+__global__ __launch_bounds__(256) void norm_act_bwd_reg(int N, int HW, int W, int C, int CG, const T* __restrict__ raw,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int act, float alpha,
+                                                        const unsigned char* __restrict__ mask, GSrc g1, GSrc g2, TView draw,
+                                                        float* __restrict__ dgamma_part, float* __restrict__ dbeta_part) {
+    constexpr int VN = VecOf<T>::N;
+    typedef typename VecOf<T>::type vec_t;
+    __shared__ __attribute__((aligned(16))) float red[2][2048];
+    const int ncg = C / CG;
+    const int lin = blockIdx.x;
+    const int n = ((lin >> 3) / ncg) * 8 + (lin & 7), cg0 = ((lin >> 3) % ncg) * CG;
+    if (n >= N) return;                                  // (whole workgroup: the grid is padded to 8 images)
+    const int VPP = CG / VN, PR = 256 / VPP;
+    const int vid = threadIdx.x % VPP, pr = threadIdx.x / VPP;
+    const int c = cg0 + vid * VN;
+    const long long pix0 = (long long)n * HW;
+    const long long base = pix0 * C + c;
+    float mu[VN], rs[VN], ga[VN], be[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        mu[k] = stats[((long long)n * C + c + k) * 2 + 0];
+        rs[k] = stats[((long long)n * C + c + k) * 2 + 1];
+        ga[k] = gamma[c + k];
+        be[k] = beta[c + k];
+    }
+    vec_t xr[PPL];
+    float d[PPL][VN];
+    float s1[VN], s2[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = pr + i * PR;
+        if (p < HW) {
+            const long long e = base + (long long)p * C;
+            float a1[VN], a2[VN], keep[VN];
+            xr[i] = *(const vec_t*)(raw + e);
+            gsrc_vload<T>(g1, pix0 + p, c, a1);
+            gsrc_vload<T>(g2, pix0 + p, c, a2);
+            if (mask) mask_vload8(mask + e, keep, VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const float xh = (to_f32((T)xr[i][k]) - mu[k]) * rs[k];
+                float a = xh * ga[k] + be[k];
+                const float kp = mask ? keep[k] : 1.f;
+                a *= kp;
+                float slope = 1.f;
+                if (act == P2P_ACT_LEAKY) slope = a > 0.f ? 1.f : alpha;
+                else if (act == P2P_ACT_RELU) slope = a > 0.f ? 1.f : 0.f;
+                d[i][k] = (a1[k] + a2[k]) * slope * kp;
+                s1[k] += d[i][k];
+                s2[k] += d[i][k] * xh;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) d[i][k] = 0.f;
+        }
+    }
+    float t1[VN], t2[VN];
+    col_reduce2<VN>(red, CG, PR, vid, pr, s1, s2, t1, t2);
+    float m1[VN], m2[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        if (pr == 0) {
+            dbeta_part[(long long)n * C + c + k] = t1[k];
+            dgamma_part[(long long)n * C + c + k] = t2[k];
+        }
+        m1[k] = t1[k] / (float)HW;
+        m2[k] = t2[k] / (float)HW;
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = pr + i * PR;
+        if (p >= HW) continue;
+        float r[VN];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            const float xh = (to_f32((T)xr[i][k]) - mu[k]) * rs[k];
+            r[k] = ga[k] * rs[k] * (d[i][k] - m1[k] - xh * m2[k]);
+        }
+        const int yy = p / W, xx = p - yy * W;
+        vstore<T>((T*)draw.ptr + draw.off(n, yy, xx) + c, r);
+    }
+}
+
+// Geometry of the register-resident form: channel group CG and pixels per thread (1, 2, 4, 8), or CG = 0 when the map
+// does not fit.
+static inline int norm_bwd_reg_geom(int Neff, int HW, int C, int vn, int& ppl_out, bool fwd = false) {
+    static int max_hw[2] = {-1, -1};          // largest map served, 0 = off (P2P_NORM_BWD_REG / P2P_NORM_FWD_REG: A/B runs)
+    if (max_hw[fwd] < 0) { const char* e = getenv(fwd ? "P2P_NORM_FWD_REG" : "P2P_NORM_BWD_REG"); max_hw[fwd] = e ? atoi(e) : 4096; }
+    ppl_out = 0;
+    if (HW > max_hw[fwd]) return 0;
+    int pick = 0, pick_ppl = 0;
+    for (int CG = 64; CG >= vn; CG >>= 1) {
+        if (CG > C || C % CG) continue;
+        const int pr = 256 / (CG / vn);
+        int ppl = (HW + pr - 1) / pr;
+        ppl = ppl <= 1 ? 1 : (ppl <= 2 ? 2 : (ppl <= 4 ? 4 : 8));
+        if ((long long)ppl * pr < HW) continue;        // more than 8 pixels per thread (c1: 16 of them on 16 workgroups were slower than the split form)
+        pick = CG; pick_ppl = ppl;
+        if ((long long)Neff * (C / CG) >= 512) break;
+    }
+    ppl_out = pick_ppl;
+    return pick;
+}
+
+// Register-resident forward (r05), the counterpart of norm_act_bwd_reg above: one launch, the input (dense, or f32 split-K slabs
+// summed in slab order and rounded through the storage type like everywhere else) is read ONCE, a thread keeps its <= 8 pixels in
+// registers between the statistics and the apply pass.  Same statistics as the two-pass form: sums shifted by the image's first
+// pixel.  At batch 4 this is what makes "split-K convolution + normalisation" cheaper than the fused block on two workgroups
+// (norm over 16 slabs: 36 -> ~10 us per layer).
+template <typename T, int PPL>
+__global__ __launch_bounds__(256) void norm_act_fwd_reg(int N, int HW, int W, int C, int CG, const void* __restrict__ raw,
+                                                        int raw_kind, int nslabs, long long slab,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int act, float alpha,
+                                                        const unsigned char* __restrict__ mask, TView out,
+                                                        T* __restrict__ raw_out, float* __restrict__ stats) {
+    constexpr int VN = VecOf<T>::N;
+    __shared__ __attribute__((aligned(16))) float red[2][2048];
+    const int ncg = C / CG;
+    const int lin = blockIdx.x;
+    const int n = ((lin >> 3) / ncg) * 8 + (lin & 7), cg0 = ((lin >> 3) % ncg) * CG;
+    if (n >= N) return;
+    const int VPP = CG / VN, PR = 256 / VPP;
+    const int vid = threadIdx.x % VPP, pr = threadIdx.x / VPP;
+    const int c = cg0 + vid * VN;
+    const long long base = (long long)n * HW * C + c;
+    float x[PPL][VN], sh[VN], s1[VN], s2[VN];
+    unsigned long long mk[PPL];
+    raw_vload<T>(raw, raw_kind, nslabs, slab, base, sh);
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = pr + i * PR;
+        mk[i] = 0;
+        if (p < HW) {
+            const long long e = base + (long long)p * C;
+            raw_vload<T>(raw, raw_kind, nslabs, slab, e, x[i]);
+            if (mask) mk[i] = VN == 8 ? *(const unsigned long long*)(mask + e) : (unsigned long long)*(const unsigned*)(mask + e);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) x[i][k] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i)
+        if (pr + i * PR < HW)
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { const float d = x[i][k] - sh[k]; s1[k] += d; s2[k] += d * d; }
+    float t1[VN], t2[VN], mu[VN], rs[VN], ga[VN], be[VN];
+    col_reduce2<VN>(red, CG, PR, vid, pr, s1, s2, t1, t2);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        const float m = t1[k] / (float)HW;
+        const float var = fmaxf(t2[k] / (float)HW - m * m, 0.f);
+        mu[k] = sh[k] + m;
+        rs[k] = rsqrtf(var + eps);
+        ga[k] = gamma[c + k];
+        be[k] = beta[c + k];
+        if (pr == 0) {
+            stats[((long long)n * C + c + k) * 2 + 0] = mu[k];
+            stats[((long long)n * C + c + k) * 2 + 1] = rs[k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = pr + i * PR;
+        if (p >= HW) continue;
+        if (raw_out) vstore<T>(raw_out + base + (long long)p * C, x[i]);
+        float y[VN];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float v = (x[i][k] - mu[k]) * rs[k] * ga[k] + be[k];
+            if (mask) v *= ((mk[i] >> (8 * k)) & 0xff) ? 2.f : 0.f;
+            if (act == P2P_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+            else if (act == P2P_ACT_RELU) v = v > 0.f ? v : 0.f;
+            y[k] = v;
+        }
+        const int yy = p / W, xx = p - yy * W;
+        vstore<T>((T*)out.ptr + out.off(n, yy, xx) + c, y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Small maps (dispatched for H*W <= 16: the 1x1 ... 4x4 layers of the U-Net bottom; 8x8 measured faster on the workgroup form).  One workgroup per (image, 64 channels) leaves
 // most lanes idle there and spends its time in barriers.  Here G = min(16, H*W) lanes own one (image, VN-channel
 // vector): each lane keeps its <= 4 pixels in registers, the statistics are exact two-pass sums combined with wave
@@ -862,6 +1057,28 @@ static int norm_act_fwd_impl(int dtype, int N, int H, int W, int C, const void* 
 #undef NF_SMALL
         return p2p_check_launch("p2p_norm_act_fwd");
     }
+    // nsplit | 0x100 (the engine's f32 parity mode): the two-pass workgroup forms only -- their order of sums does not depend on N,
+    // and the parity gate (tests/test_train_step_gpu.py, 1e-4 on every gradient tensor at batch 2) holds only while no ReLU gate
+    // flips against the f64 oracle: a forward pass that rounds differently by a few ulp flips one (a 1e-2 error on a weight gradient)
+    const bool legacy = nsplit > 0 && (nsplit & 0x100);
+    const int n_geom = (nsplit > 0 && (nsplit & 0x200)) ? 256 : N;      // | 0x200: the register-resident geometry of batch 256 (tests)
+    if (nsplit > 0) nsplit &= 0xff;
+    if (vec && gamma && !tail && nsplit >= 0 && !legacy) {
+        int ppl = 0;
+        const int rcg = norm_bwd_reg_geom(n_geom, H * W, C, vn, ppl, true);
+        if (rcg) {
+            hipStream_t st = (hipStream_t)stream;
+            const dim3 grid((unsigned)(((N + 7) / 8) * 8 * (C / rcg)));
+#define NF_REG(P_) norm_act_fwd_reg<T, P_><<<grid, 256, 0, st>>>(N, H * W, W, C, rcg, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, \
+                                                                mask, make_view(out), (T*)raw_out, stats)
+            if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NF_REG(1)); }
+            else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NF_REG(2)); }
+            else if (ppl == 4) { P2P_DISPATCH_DTYPE(dtype, NF_REG(4)); }
+            else { P2P_DISPATCH_DTYPE(dtype, NF_REG(8)); }
+#undef NF_REG
+            return p2p_check_launch("p2p_norm_act_fwd");
+        }
+    }
     if (vec) {
         int CG = C > 64 ? 64 : C;
         while (C % CG) CG -= vn;
@@ -961,6 +1178,26 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
         else { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(4)); }
 #undef NB_SMALL
         return p2p_check_launch("p2p_norm_act_bwd");
+    }
+    // nsplit | 0x100 (the engine's f32 parity mode): the two-pass workgroup forms only (see norm_act_fwd_impl)
+    const bool legacy = nsplit > 0 && (nsplit & 0x100);
+    const int n_geom = (nsplit > 0 && (nsplit & 0x200)) ? 256 : N;      // | 0x200: the register-resident geometry of batch 256 (tests)
+    if (nsplit > 0) nsplit &= 0xff;
+    if (vec && !legacy) {
+        int ppl = 0;
+        const int rcg = norm_bwd_reg_geom(n_geom, H * W, C, vn, ppl);
+        if (rcg) {
+            hipStream_t st = (hipStream_t)stream;
+            const dim3 grid((unsigned)(((N + 7) / 8) * 8 * (C / rcg)));
+#define NB_REG(P_) P2P_LAUNCH_LAST((norm_act_bwd_reg<T, P_>), grid, dim3(256), 0, st, N, H * W, W, C, rcg, (const T*)raw, stats, gamma, beta, act, \
+                                   alpha, mask, make_gsrc(g1), make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)
+            if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NB_REG(1)); }
+            else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NB_REG(2)); }
+            else if (ppl == 4) { P2P_DISPATCH_DTYPE(dtype, NB_REG(4)); }
+            else { P2P_DISPATCH_DTYPE(dtype, NB_REG(8)); }
+#undef NB_REG
+            return p2p_check_launch("p2p_norm_act_bwd");
+        }
     }
     if (vec) {
         int CG = C > 64 ? 64 : C;

@@ -498,7 +498,9 @@ class Pix2PixEngine:
         self.batch_invariant = dtype == L.F32 and os.environ.get("P2P_BATCH_INVARIANT", "1") != "0"
         self.wgemm_pipe = os.environ.get("P2P_WGEMM_PIPE", "1") != "0"
         self.wgemm_want_pipe = int(os.environ.get("P2P_WGEMM_WANT_PIPE", "256"))
-        self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "256"))   # workgroups wanted per implicit-GEMM launch
+        # workgroups wanted per implicit-GEMM launch; 0 = by batch (_splitk): every extra K slice is another f32 slab that the
+        # layer's consumers (normalisation forward / backward) read, which is what a launch-bound small batch pays for
+        self.splitk_target = int(os.environ.get("P2P_SPLITK_TARGET", "0"))
         self._prep_table = {}
         self._head_prepped = False
         # partial-pixel stores (the source channels of the last concat buffer, the halves of the discriminator's fake pixel) are
@@ -783,8 +785,10 @@ class Pix2PixEngine:
         esz = 2 if self.dtype == L.BF16 else 4
         bn = 128 if ncols % 128 == 0 else (64 if ncols % 64 == 0 else 32)
         blocks = ((B * lh * lh + 127) // 128) * (ncols // bn) * (1 if op == L.OP_G else 4)
+        # measured (profiles/r05_exp_small_batch.txt, whole step): 64 is the fastest target up to batch 16, 128 at 32, 256 from 64 on
+        target = self.splitk_target or (64 if B <= 16 else (128 if B <= 32 else 256))
         sk = 1
-        while blocks * sk < self.splitk_target and sk * 2 <= ntaps and ((ntaps // (sk * 2)) * cc * esz) % 128 == 0:
+        while blocks * sk < target and sk * 2 <= ntaps and ((ntaps // (sk * 2)) * cc * esz) % 128 == 0:
             sk *= 2
         return sk
 
@@ -987,14 +991,15 @@ class Pix2PixEngine:
         image from HBM in its second launch, where the one-launch form re-reads it from L2, so it only pays for the
         backward kernel (three input streams) when there would be fewer than ~1024 workgroups (4 per CU)."""
         if not bwd:
-            return 1
+            return 0x101 if self.batch_invariant else 1
         if self.batch_invariant:
             N = 256
         groups = max(1, c // 64)
         sp = 1
         while N * groups * sp < 1024 and res * res // (sp * 2) >= 64 and sp < 16:
             sp *= 2
-        return sp
+        # | 0x100: the two-pass forms only (the register-resident ones pick their geometry, i.e. the order of the sums, by batch)
+        return sp | 0x100 if self.batch_invariant else sp
 
     def _norm_fwd(self, P, N, res, c, raw_buf, rk, gamma, beta, act, mask, out_view, stats, tail=None):
         """tail: view whose src_ch channels are copied behind this layer's channels in out_view (see _c6_tail)"""
