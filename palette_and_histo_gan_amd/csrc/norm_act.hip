@@ -178,14 +178,33 @@ __device__ __forceinline__ void vstore(T* p, const float* v) {
     *(typename VecOf<T>::type*)p = r;
 }
 
-template <typename T>
+// SLABS: 1 = f32 split-K slabs summed one by one (the two-pass kernels: the unrolled form below costs them registers -- the
+// 64x64x32 backward launch of c2 went 68 -> 96 us with it), 4 = four slabs per trip, 0 = dense input only (the slab code and
+// its registers are compiled out: the host picks the instantiation by what the launch reads).
+template <typename T, int SLABS = 1>
 __device__ __forceinline__ void raw_vload(const void* raw, int raw_kind, int nslabs, long long slab, long long e, float* v) {
     constexpr int VN = VecOf<T>::N;
-    if (raw_kind == 1) { vload<T>((const T*)raw + e, v); return; }
+    if (SLABS == 0 || raw_kind == 1) { vload<T>((const T*)raw + e, v); return; }
 #pragma unroll
     for (int k = 0; k < VN; ++k) v[k] = 0.f;
     const float* p = (const float*)raw + e;
-    for (int sIdx = 0; sIdx < nslabs; ++sIdx) {
+    // four slabs per trip: their loads are issued together, the sums keep the slab order (a small batch reads 4-16 slabs per
+    // element and the one-slab loop was a chain of dependent memory latencies: c1 14 us for 32 K elements)
+    int sIdx = 0;
+    for (; SLABS == 4 && sIdx + 4 <= nslabs; sIdx += 4) {
+        f32x4 r[4][VN / 4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < VN; k += 4) r[u][k / 4] = *(const f32x4*)(p + (long long)(sIdx + u) * slab + k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < VN; k += 4) {
+                v[k] += r[u][k / 4][0]; v[k + 1] += r[u][k / 4][1]; v[k + 2] += r[u][k / 4][2]; v[k + 3] += r[u][k / 4][3];
+            }
+    }
+    for (; sIdx < nslabs; ++sIdx) {
 #pragma unroll
         for (int k = 0; k < VN; k += 4) {
             f32x4 r = *(const f32x4*)(p + (long long)sIdx * slab + k);
@@ -196,7 +215,7 @@ __device__ __forceinline__ void raw_vload(const void* raw, int raw_kind, int nsl
     for (int k = 0; k < VN; ++k) v[k] = to_f32(from_f32<T>(v[k]));
 }
 
-template <typename T>
+template <typename T, int SLABS = 1>
 __device__ __forceinline__ void gsrc_vload(const GSrc& g, long long pix, int c, float* v) {
     constexpr int VN = VecOf<T>::N;
     if (g.kind == 0) {
@@ -205,11 +224,27 @@ __device__ __forceinline__ void gsrc_vload(const GSrc& g, long long pix, int c, 
         return;
     }
     long long e = pix * g.ld + g.coff + c;
-    if (g.kind == 1) { vload<T>((const T*)g.ptr + e, v); return; }
+    if (SLABS == 0 || g.kind == 1) { vload<T>((const T*)g.ptr + e, v); return; }
 #pragma unroll
     for (int k = 0; k < VN; ++k) v[k] = 0.f;
     const float* p = (const float*)g.ptr + e;
-    for (int sIdx = 0; sIdx < g.nslabs; ++sIdx)
+    int sIdx = 0;
+    if (SLABS == 4 && (g.slab & 3) == 0 && (e & 3) == 0 && ((uintptr_t)g.ptr & 15) == 0) {         // whole 16-byte loads, four slabs per trip, sums in slab order (see raw_vload)
+        for (; sIdx + 4 <= g.nslabs; sIdx += 4) {
+            f32x4 r[4][VN / 4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < VN; k += 4) r[u][k / 4] = *(const f32x4*)(p + (long long)(sIdx + u) * g.slab + k);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < VN; k += 4) {
+                    v[k] += r[u][k / 4][0]; v[k + 1] += r[u][k / 4][1]; v[k + 2] += r[u][k / 4][2]; v[k + 3] += r[u][k / 4][3];
+                }
+        }
+    }
+    for (; sIdx < g.nslabs; ++sIdx)
 #pragma unroll
         for (int k = 0; k < VN; ++k) v[k] += p[(long long)sIdx * g.slab + k];
 }
@@ -554,7 +589,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_vec(int H, int W, int C, int
 // instead of 16 workgroups looping twice over 16 pixels (c1: 29 us for two launches -> one launch-sized kernel).  The channel
 // groups of one image sit on ONE XCD, next to each other in dispatch order (workgroup id = ((n / 8) * groups + group) * 8 + n % 8):
 // with groups narrower than a 128-byte line the line's other readers find it in that XCD's L2.
-template <typename T, int PPL>
+template <typename T, int PPL, int SLABS>
 __global__ __launch_bounds__(256) void norm_act_bwd_reg(int N, int HW, int W, int C, int CG, const T* __restrict__ raw,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int act, float alpha,
@@ -592,8 +627,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_reg(int N, int HW, int W, in
             const long long e = base + (long long)p * C;
             float a1[VN], a2[VN], keep[VN];
             xr[i] = *(const vec_t*)(raw + e);
-            gsrc_vload<T>(g1, pix0 + p, c, a1);
-            gsrc_vload<T>(g2, pix0 + p, c, a2);
+            gsrc_vload<T, SLABS>(g1, pix0 + p, c, a1);
+            gsrc_vload<T, SLABS>(g2, pix0 + p, c, a2);
             if (mask) mask_vload8(mask + e, keep, VN);
 #pragma unroll
             for (int k = 0; k < VN; ++k) {
@@ -666,7 +701,7 @@ static inline int norm_bwd_reg_geom(int Neff, int HW, int C, int vn, int& ppl_ou
 // registers between the statistics and the apply pass.  Same statistics as the two-pass form: sums shifted by the image's first
 // pixel.  At batch 4 this is what makes "split-K convolution + normalisation" cheaper than the fused block on two workgroups
 // (norm over 16 slabs: 36 -> ~10 us per layer).
-template <typename T, int PPL>
+template <typename T, int PPL, int SLABS>
 __global__ __launch_bounds__(256) void norm_act_fwd_reg(int N, int HW, int W, int C, int CG, const void* __restrict__ raw,
                                                         int raw_kind, int nslabs, long long slab,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -685,14 +720,14 @@ __global__ __launch_bounds__(256) void norm_act_fwd_reg(int N, int HW, int W, in
     const long long base = (long long)n * HW * C + c;
     float x[PPL][VN], sh[VN], s1[VN], s2[VN];
     unsigned long long mk[PPL];
-    raw_vload<T>(raw, raw_kind, nslabs, slab, base, sh);
+    raw_vload<T, SLABS>(raw, raw_kind, nslabs, slab, base, sh);
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int p = pr + i * PR;
         mk[i] = 0;
         if (p < HW) {
             const long long e = base + (long long)p * C;
-            raw_vload<T>(raw, raw_kind, nslabs, slab, e, x[i]);
+            raw_vload<T, SLABS>(raw, raw_kind, nslabs, slab, e, x[i]);
             if (mask) mk[i] = VN == 8 ? *(const unsigned long long*)(mask + e) : (unsigned long long)*(const unsigned*)(mask + e);
         } else {
 #pragma unroll
@@ -745,7 +780,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_reg(int N, int HW, int W, in
 // most lanes idle there and spends its time in barriers.  Here G = min(16, H*W) lanes own one (image, VN-channel
 // vector): each lane keeps its <= 4 pixels in registers, the statistics are exact two-pass sums combined with wave
 // shuffles inside the lane group (no LDS, no barrier), and the result is written in the same pass.
-template <typename T, int PPL>
+template <typename T, int PPL, int SLABS>
 __global__ __launch_bounds__(256) void norm_act_fwd_small(int HW, int W, int C, int lgG, long long items, const void* __restrict__ raw,
                                                           int raw_kind, int nslabs, long long slab, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, int act, float alpha,
@@ -764,7 +799,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_small(int HW, int W, int C, 
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int p = g + i * G;
-        if (p < HW) raw_vload<T>(raw, raw_kind, nslabs, slab, base + (long long)p * C, x[i]);
+        if (p < HW) raw_vload<T, SLABS>(raw, raw_kind, nslabs, slab, base + (long long)p * C, x[i]);
         else {
 #pragma unroll
             for (int k = 0; k < VN; ++k) x[i][k] = 0.f;
@@ -814,7 +849,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_small(int HW, int W, int C, 
     }
 }
 
-template <typename T, int PPL>
+template <typename T, int PPL, int SLABS>
 __global__ __launch_bounds__(256) void norm_act_bwd_small(int HW, int W, int C, int lgG, long long items, const T* __restrict__ raw,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, float alpha,
@@ -845,8 +880,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_small(int HW, int W, int C, 
             const long long e = base + (long long)p * C;
             float x[VN], a1[VN], a2[VN], keep[VN];
             vload<T>(raw + e, x);
-            gsrc_vload<T>(g1, pix0 + p, c, a1);
-            gsrc_vload<T>(g2, pix0 + p, c, a2);
+            gsrc_vload<T, SLABS>(g1, pix0 + p, c, a1);
+            gsrc_vload<T, SLABS>(g2, pix0 + p, c, a2);
             if (mask) mask_vload8(mask + e, keep, VN);
 #pragma unroll
             for (int k = 0; k < VN; ++k) {
@@ -1049,12 +1084,14 @@ static int norm_act_fwd_impl(int dtype, int N, int H, int W, int C, const void* 
         const long long threads = items << lgG;
         const dim3 grid((unsigned)((threads + 255) / 256));
         hipStream_t st = (hipStream_t)stream;
-#define NF_SMALL(P_) norm_act_fwd_small<T, P_><<<grid, 256, 0, st>>>(H * W, W, C, lgG, items, raw, raw_kind, nslabs, slab_stride, gamma, \
+#define NF_SMALL2(P_, S_) norm_act_fwd_small<T, P_, S_><<<grid, 256, 0, st>>>(H * W, W, C, lgG, items, raw, raw_kind, nslabs, slab_stride, gamma, \
                                                                    beta, eps, act, alpha, mask, make_view(out), (T*)raw_out, stats)
+#define NF_SMALL(P_) do { if (raw_kind == 2) NF_SMALL2(P_, 4); else NF_SMALL2(P_, 0); } while (0)
         if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NF_SMALL(1)); }
         else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NF_SMALL(2)); }
         else { P2P_DISPATCH_DTYPE(dtype, NF_SMALL(4)); }
 #undef NF_SMALL
+#undef NF_SMALL2
         return p2p_check_launch("p2p_norm_act_fwd");
     }
     // nsplit | 0x100 (the engine's f32 parity mode): the two-pass workgroup forms only -- their order of sums does not depend on N,
@@ -1069,13 +1106,15 @@ static int norm_act_fwd_impl(int dtype, int N, int H, int W, int C, const void* 
         if (rcg) {
             hipStream_t st = (hipStream_t)stream;
             const dim3 grid((unsigned)(((N + 7) / 8) * 8 * (C / rcg)));
-#define NF_REG(P_) norm_act_fwd_reg<T, P_><<<grid, 256, 0, st>>>(N, H * W, W, C, rcg, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, \
+#define NF_REG2(P_, S_) norm_act_fwd_reg<T, P_, S_><<<grid, 256, 0, st>>>(N, H * W, W, C, rcg, raw, raw_kind, nslabs, slab_stride, gamma, beta, eps, act, alpha, \
                                                                 mask, make_view(out), (T*)raw_out, stats)
+#define NF_REG(P_) do { if (raw_kind == 2) NF_REG2(P_, 4); else NF_REG2(P_, 0); } while (0)
             if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NF_REG(1)); }
             else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NF_REG(2)); }
             else if (ppl == 4) { P2P_DISPATCH_DTYPE(dtype, NF_REG(4)); }
             else { P2P_DISPATCH_DTYPE(dtype, NF_REG(8)); }
 #undef NF_REG
+#undef NF_REG2
             return p2p_check_launch("p2p_norm_act_fwd");
         }
     }
@@ -1164,6 +1203,7 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
     };
     const bool vec = gamma && C % 8 == 0 && draw->ld % vn == 0 && ((uintptr_t)draw->ptr % 16) == 0 &&
                      ((uintptr_t)raw % 16) == 0 && gs_ok(g1) && gs_ok(g2);
+    const bool g_slabs = (g1 && g1->kind == 2) || (g2 && g2->kind == 2);      // picks the instantiation with the f32-slab loader
     if (vec && H * W <= 16) {
         int lgG, ppl;
         small_geom(H * W, lgG, ppl);
@@ -1171,12 +1211,14 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
         const long long threads = items << lgG;
         const dim3 grid((unsigned)((threads + 255) / 256));
         hipStream_t st = (hipStream_t)stream;
-#define NB_SMALL(P_) P2P_LAUNCH_LAST((norm_act_bwd_small<T, P_>), grid, dim3(256), 0, st, H * W, W, C, lgG, items, (const T*)raw, stats, gamma, beta, act, \
+#define NB_SMALL2(P_, S_) P2P_LAUNCH_LAST((norm_act_bwd_small<T, P_, S_>), grid, dim3(256), 0, st, H * W, W, C, lgG, items, (const T*)raw, stats, gamma, beta, act, \
                                      alpha, mask, make_gsrc(g1), make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)
+#define NB_SMALL(P_) do { if (g_slabs) NB_SMALL2(P_, 4); else NB_SMALL2(P_, 0); } while (0)
         if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(1)); }
         else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(2)); }
         else { P2P_DISPATCH_DTYPE(dtype, NB_SMALL(4)); }
 #undef NB_SMALL
+#undef NB_SMALL2
         return p2p_check_launch("p2p_norm_act_bwd");
     }
     // nsplit | 0x100 (the engine's f32 parity mode): the two-pass workgroup forms only (see norm_act_fwd_impl)
@@ -1189,13 +1231,15 @@ extern "C" int p2p_norm_act_bwd(int dtype, int N, int H, int W, int C, const voi
         if (rcg) {
             hipStream_t st = (hipStream_t)stream;
             const dim3 grid((unsigned)(((N + 7) / 8) * 8 * (C / rcg)));
-#define NB_REG(P_) P2P_LAUNCH_LAST((norm_act_bwd_reg<T, P_>), grid, dim3(256), 0, st, N, H * W, W, C, rcg, (const T*)raw, stats, gamma, beta, act, \
+#define NB_REG2(P_, S_) P2P_LAUNCH_LAST((norm_act_bwd_reg<T, P_, S_>), grid, dim3(256), 0, st, N, H * W, W, C, rcg, (const T*)raw, stats, gamma, beta, act, \
                                    alpha, mask, make_gsrc(g1), make_gsrc(g2), make_view(draw), dgamma_part, dbeta_part)
+#define NB_REG(P_) do { if (g_slabs) NB_REG2(P_, 4); else NB_REG2(P_, 0); } while (0)
             if (ppl == 1) { P2P_DISPATCH_DTYPE(dtype, NB_REG(1)); }
             else if (ppl == 2) { P2P_DISPATCH_DTYPE(dtype, NB_REG(2)); }
             else if (ppl == 4) { P2P_DISPATCH_DTYPE(dtype, NB_REG(4)); }
             else { P2P_DISPATCH_DTYPE(dtype, NB_REG(8)); }
 #undef NB_REG
+#undef NB_REG2
             return p2p_check_launch("p2p_norm_act_bwd");
         }
     }
