@@ -680,6 +680,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_reg(int N, int HW, int W, in
 static inline int norm_bwd_reg_geom(int Neff, int HW, int C, int vn, int& ppl_out, bool fwd = false) {
     static int max_hw[2] = {-1, -1};          // largest map served, 0 = off (P2P_NORM_BWD_REG / P2P_NORM_FWD_REG: A/B runs)
     if (max_hw[fwd] < 0) { const char* e = getenv(fwd ? "P2P_NORM_FWD_REG" : "P2P_NORM_BWD_REG"); max_hw[fwd] = e ? atoi(e) : 4096; }
+    static int min_wgs = -1;                  // workgroups wanted before a wider channel group is accepted (P2P_NORM_REG_WGS: sweeps)
+    if (min_wgs < 0) { const char* e = getenv("P2P_NORM_REG_WGS"); min_wgs = e ? atoi(e) : 512; }
     ppl_out = 0;
     if (HW > max_hw[fwd]) return 0;
     int pick = 0, pick_ppl = 0;
@@ -690,7 +692,7 @@ static inline int norm_bwd_reg_geom(int Neff, int HW, int C, int vn, int& ppl_ou
         ppl = ppl <= 1 ? 1 : (ppl <= 2 ? 2 : (ppl <= 4 ? 4 : 8));
         if ((long long)ppl * pr < HW) continue;        // more than 8 pixels per thread (c1: 16 of them on 16 workgroups were slower than the split form)
         pick = CG; pick_ppl = ppl;
-        if ((long long)Neff * (C / CG) >= 512) break;
+        if ((long long)Neff * (C / CG) >= min_wgs) break;
     }
     ppl_out = pick_ppl;
     return pick;
