@@ -15,7 +15,7 @@ from collections import defaultdict
 # kernel-name fragments, matched LONGEST FIRST against the demangled or mangled name (r04: "igemm_kernel" is not a substring of
 # "igemm_pipe_kernel" and "wgemm_kernel" is not one of "wgemm_pipe_kernel": the round's two new kernels fell out of the summaries)
 FAMILIES = ["brig_kernel", "igemm_pipe_kernel", "igemm_kernel", "wgemm_pipe_kernel", "wgemm_kernel", "wgrad_small_kernel", "conv_strip_kernel",
-            "conv_fewin_kernel", "conv_fewout_kernel", "norm_act_fwd_vec", "norm_act_bwd_vec", "norm_act_fwd_small", "norm_act_bwd_small",
+            "conv_fewin_kernel", "conv_fewout_kernel", "norm_act_fwd_vec", "norm_act_bwd_vec", "norm_act_fwd_small", "norm_act_bwd_small", "norm_act_fwd_reg", "norm_act_bwd_reg",
             "adam_flat_dev_kernel", "weight_prep_batched_kernel", "act_bwd_vec_kernel", "pack_pair_kernel", "pack_pair_idx_kernel",
             "ws_slab_sum_kernel", "slab_sum_kernel", "rgbuv_hist_fwd_kernel", "rgbuv_hist_bwd_kernel", "softmax256_kernel",
             "rgbuv_hist_fwd3_kernel", "rgbuv_hist_bwd3_kernel", "rgbuv_hist_fold_kernel", "hist_grad_prep_kernel", "rgbuv_points_kernel",

@@ -19,6 +19,7 @@ FAMILIES = {"igemm_pipe_kernel": ("p2p_igemm", True), "igemm_kernel": ("p2p_igem
             "ws_slab_sum_kernel": ("p2p_wgrad_small", False), "slab_sum_kernel": ("p2p_wgemm", False),
             "norm_act_fwd_vec": ("p2p_norm_act_fwd", True), "norm_act_fwd_small": ("p2p_norm_act_fwd", True),
             "norm_act_bwd_vec": ("p2p_norm_act_bwd", True), "norm_act_bwd_small": ("p2p_norm_act_bwd", True),
+            "norm_act_fwd_reg": ("p2p_norm_act_fwd", True), "norm_act_bwd_reg": ("p2p_norm_act_bwd", True),
             "adam_flat_dev_kernel": ("p2p_adam_flat_dev", True),
             "weight_prep_kernel": ("p2p_weight_prep_pad", True), "rgbuv_hist_fwd_kernel": ("p2p_rgbuv_hist_fwd", True),
             "rgbuv_hist_bwd_kernel": ("p2p_rgbuv_hist_hellinger_bwd", True), "rgbuv_hist_fwd3_kernel": ("p2p_rgbuv_hist_fwd3", True),
