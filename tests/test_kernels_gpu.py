@@ -197,7 +197,8 @@ def test_wgemm(dtype, n, lh, cg, cd, msplit):
     assert U.rel_err(dw.cpu().numpy().reshape(4, 4, cg, cd), w_ref) < 2e-5
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+# (dtype, channels in front of the slice): 4 = not a whole bf16 vector (scalar forward kernel), 8 = the vector forms; f32: 4 is a vector
+@pytest.mark.parametrize("dtype,pad", [(L.F32, 4), (L.BF16, 4), (L.BF16, 8)])
 @pytest.mark.parametrize("n,h,c,act,use_mask,norm,nsplit", [
     (2, 4, 64, L.ACT_LEAKY, False, True, 1), (3, 8, 32, L.ACT_RELU, True, True, 1), (2, 1, 512, L.ACT_LEAKY, False, True, 4),
     (2, 4, 36, L.ACT_RELU, True, True, 1), (2, 8, 64, L.ACT_LEAKY, False, False, 2), (2, 32, 32, L.ACT_RELU, False, True, 4),
@@ -212,7 +213,7 @@ def test_wgemm(dtype, n, lh, cg, cd, msplit):
     (3, 16, 64, L.ACT_LEAKY, True, True, 0x201), (2, 32, 32, L.ACT_RELU, False, True, 0x201),
     # nsplit | 0x100 (the engine's f32 parity mode): the two-pass forms, whatever the map
     (2, 16, 128, L.ACT_RELU, False, True, 0x102), (3, 8, 256, L.ACT_RELU, True, True, 0x101)])
-def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm, nsplit):
+def test_norm_act_fwd_bwd(dtype, pad, n, h, c, act, use_mask, norm, nsplit):
     rng = np.random.default_rng(13)
     nws = torch.empty(n * 16 * c * 2, dtype=torch.float32, device=U.DEV)
     x = U.q(rng.normal(size=(n, h, h, c)) * 2 + 0.3, dtype)
@@ -220,7 +221,7 @@ def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm, nsplit):
     beta = (0.2 * rng.normal(size=c)).astype(np.float32)
     mask = rng.integers(0, 2, size=(n, h, h, c)).astype(np.uint8) if use_mask else None
     dy1 = U.q(rng.normal(size=(n, h, h, c + 8)), dtype)       # gradient sources with channel offset / f32 slabs
-    dy2 = rng.normal(size=(2, n, h, h, c)).astype(np.float32)
+    dy2 = rng.normal(size=(5, n, h, h, c)).astype(np.float32)       # five f32 slabs: one four-slab trip of the loader + its remainder loop
     xt = torch.tensor(x, dtype=F64, requires_grad=True)
     gt = torch.tensor(gamma, dtype=F64, requires_grad=True)
     bt = torch.tensor(beta, dtype=F64, requires_grad=True)
@@ -233,22 +234,22 @@ def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm, nsplit):
 
     raw = E.DenseBuf(n, h, h, c, U.tdt(dtype), U.DEV)
     raw.t.copy_(U.dev(x.reshape(-1, c), U.tdt(dtype)))
-    out = E.HaloBuf(n, h, h, c + 4, dtype, U.DEV)
+    out = E.HaloBuf(n, h, h, c + pad, dtype, U.DEV)
     stats = torch.empty((n, c, 2), dtype=torch.float32, device=U.DEV)
     g_d, b_d = U.dev(gamma), U.dev(beta)
     mask_d = U.dev(mask.reshape(-1, c), torch.uint8) if use_mask else None
     L.call("p2p_norm_act_fwd", dtype, n, h, h, c, raw.ptr(), 1, 1, 0, U.ptr(g_d) if norm else None,
-           U.ptr(b_d) if norm else None, 1e-3, act, 0.3, U.ptr(mask_d) if use_mask else None, C.byref(out.view(coff=4)),
+           U.ptr(b_d) if norm else None, 1e-3, act, 0.3, U.ptr(mask_d) if use_mask else None, C.byref(out.view(coff=pad)),
            None, U.ptr(stats) if norm else None, U.ptr(nws), nws.numel() * 4, nsplit, U.stream())
     got = U.halo_to_np(out)
-    assert np.count_nonzero(got[..., :4]) == 0
-    assert U.rel_err(got[..., 4:], y.detach().numpy()) < OUT_TOL[dtype]
+    assert np.count_nonzero(got[..., :pad]) == 0
+    assert U.rel_err(got[..., pad:], y.detach().numpy()) < OUT_TOL[dtype]
     assert float(out.t.float().abs().sum()) == pytest.approx(float(np.abs(got).sum()), rel=1e-6)   # halo untouched
 
     g1 = E.DenseBuf(n, h, h, c + 8, U.tdt(dtype), U.DEV)
     g1.t.copy_(U.dev(dy1.reshape(-1, c + 8), U.tdt(dtype)))
     g2 = U.dev(dy2.reshape(-1))
-    gs2 = L.GSrc(g2.data_ptr(), 2, 2, n * h * h * c, c, 0)
+    gs2 = L.GSrc(g2.data_ptr(), 2, 5, n * h * h * c, c, 0)
     draw = E.HaloBuf(n, h, h, c, dtype, U.DEV)
     part = torch.zeros((2, n, c), dtype=torch.float32, device=U.DEV)
     L.call("p2p_norm_act_bwd", dtype, n, h, h, c, raw.ptr(), U.ptr(stats) if norm else None,
@@ -265,6 +266,38 @@ def test_norm_act_fwd_bwd(dtype, n, h, c, act, use_mask, norm, nsplit):
         L.call("p2p_colsum", U.ptr(part[0]), n, c, 1.0, U.ptr(dbet), U.stream())
         assert U.rel_err(dgam.cpu().numpy(), gt.grad.numpy()) < 1e-4
         assert U.rel_err(dbet.cpu().numpy(), bt.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,c,nslabs", [(2, 4, 64, 16), (3, 2, 512, 7), (2, 8, 256, 5), (3, 16, 128, 4), (2, 32, 64, 2), (2, 64, 32, 3)])
+def test_norm_act_fwd_from_split_k_slabs(dtype, n, h, c, nslabs):
+    """The forward kernels fed by a K-split convolution (raw_kind 2): the f32 slabs are summed in slab order, rounded through the
+    activation dtype (written to raw_out: what the backward pass reads) and normalised -- the lane-group form (4x4, 2x2), the
+    register-resident form with the four-slabs-per-trip loader and its remainder loop (8x8 ... 32x32) and the two-pass form (64x64)."""
+    rng = np.random.default_rng(17)
+    slabs = (rng.normal(size=(nslabs, n, h, h, c)) * 0.8 + 0.1).astype(np.float32)
+    acc = np.zeros((n, h, h, c), np.float32)
+    for k in range(nslabs):
+        acc = acc + slabs[k]                      # f32, slab order: bit for bit what the loader computes
+    x = U.q(acc, dtype)
+    gamma = (1 + 0.2 * rng.normal(size=c)).astype(np.float32)
+    beta = (0.2 * rng.normal(size=c)).astype(np.float32)
+    y = rg.leaky_relu(rg.instance_norm(torch.tensor(x, dtype=F64), torch.tensor(gamma, dtype=F64), torch.tensor(beta, dtype=F64))).numpy()
+    slabs_d = U.dev(slabs.reshape(-1))
+    raw_out = E.DenseBuf(n, h, h, c, U.tdt(dtype), U.DEV)
+    raw_out.t.fill_(float("nan"))
+    out = E.HaloBuf(n, h, h, c + 8, dtype, U.DEV)
+    stats = torch.empty((n, c, 2), dtype=torch.float32, device=U.DEV)
+    nws = torch.empty(n * 16 * c * 2, dtype=torch.float32, device=U.DEV)
+    g_d, b_d = U.dev(gamma), U.dev(beta)
+    L.call("p2p_norm_act_fwd", dtype, n, h, h, c, U.ptr(slabs_d), 2, nslabs, n * h * h * c, U.ptr(g_d), U.ptr(b_d), 1e-3, L.ACT_LEAKY, 0.3,
+           None, C.byref(out.view(coff=8)), raw_out.ptr(), U.ptr(stats), U.ptr(nws), nws.numel() * 4, 1, U.stream())
+    assert np.array_equal(U.dense_to_np(raw_out), x)
+    got = U.halo_to_np(out)
+    assert np.count_nonzero(got[..., :8]) == 0
+    assert U.rel_err(got[..., 8:], y) < OUT_TOL[dtype]
+    mean = x.astype(np.float64).mean(axis=(1, 2))
+    assert np.abs(stats[..., 0].cpu().numpy() - mean).max() < 1e-5 * max(1.0, np.abs(mean).max())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
