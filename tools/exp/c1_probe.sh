@@ -1,24 +1,22 @@
-# probes, round 5 (run through gpurun from the repository root): workgroups wanted by the register-resident InstanceNorm kernels
+# probe, round 5 (run through gpurun from the repository root): the early part of Adam on an optimizer stream beside the rest of the tail
 set -e
 mkdir -p gpurun_out/r05n
 O=gpurun_out/r05n
+timeout -k 10 900 python -m pytest tests/test_train_step_gpu.py tests/test_dp_gpu.py tests/test_models_gpu.py -x -q -m gpu > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
+tail -2 $O/tests.log
 run() {  # config, tag, env...
   cfg=$1; tag=$2; shift; shift
   st=300; [ $cfg = c1 ] || st=100
-  env "$@" timeout -k 10 300 python bench.py --config $cfg --steps $st --warmup 20 --no-cpu-baseline --no-feed-profile --detail $O/percall_${cfg}_$tag.txt > $O/bench_${cfg}_$tag.json 2>$O/bench_${cfg}_$tag.err
+  env "$@" timeout -k 10 300 python bench.py --config $cfg --steps $st --warmup 20 --no-cpu-baseline --no-feed-profile --no-profile > $O/bench_${cfg}_$tag.json 2>$O/bench_${cfg}_$tag.err
   python -c "
 import json
 d=json.loads(open('$O/bench_${cfg}_$tag.json').read().strip().splitlines()[-1])
-k=d['kernel_ms_per_step']
-print('$cfg $tag', d['value'], d['ms_per_step'], 'norm_fwd', k.get('p2p_norm_act_fwd'), 'norm_bwd', k.get('p2p_norm_act_bwd'), 'serial', d.get('serialised_kernel_ms'))"
+print('$cfg $tag', d['value'], d['ms_per_step'])"
 }
-for w in 512 1024 2048 4096 256 512; do
-  run c2 w$w P2P_NORM_REG_WGS=$w
+for cfg in c1 c2 c3 c4 c5; do
+  run $cfg on A=1
+  run $cfg off P2P_TAIL_OVERLAP=0
+  run $cfg on2 A=1
+  run $cfg off2 P2P_TAIL_OVERLAP=0
 done
-run c2 off P2P_NORM_FWD_REG=0 P2P_NORM_BWD_REG=0
-run c4 w512 P2P_NORM_REG_WGS=512
-run c4 w2048 P2P_NORM_REG_WGS=2048
-run c5 w512 P2P_NORM_REG_WGS=512
-run c5 w2048 P2P_NORM_REG_WGS=2048
-run c5 off P2P_NORM_FWD_REG=0 P2P_NORM_BWD_REG=0
 echo done
