@@ -1,4 +1,6 @@
-# probe, round 5 (run through gpurun from the repository root): the early part of Adam on an optimizer stream beside the rest of the tail
+# probe, round 5 (run through gpurun from the repository root), last form: the early part of Adam on an optimizer stream beside the rest of
+# the tail -- with tools/exp/tail_overlap.patch applied (P2P_TAIL_OVERLAP does not exist in the tree).  Earlier forms of this script ran the
+# A/B matrices of profiles/r05_exp_small_batch.txt (fused block on / off, K-split targets, norm kernel switches, batch sweep).
 set -e
 mkdir -p gpurun_out/r05n
 O=gpurun_out/r05n
