@@ -11,6 +11,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 eng = E.Pix2PixEngine(4, 4, "tanh", 64, L.BF16, device="cuda:0", seed=47)
 src, tgt = DU.synthetic_rgba_batch(np.random.default_rng([47, 0]), B, 64, palette_size=None)
 s_d, t_d = torch.as_tensor(src).cuda(), torch.as_tensor(tgt).cuda()
+if len(sys.argv) > 2 and sys.argv[2] == "burn":        # 0.3 s of dense bf16 matmuls first: is the ramp the chip's (clocks) or the step's?
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(60):
+        a @ a
+    t1.record(); torch.cuda.synchronize()
+    print("burn %.0f ms" % t0.elapsed_time(t1))
 for rep in range(3):
     for _ in range(5):
         eng.train_step_rgba(s_d, t_d, 100.0)
